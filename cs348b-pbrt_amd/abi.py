@@ -1,0 +1,207 @@
+"""ctypes mirror of include/pvol.h (the C-ABI boundary) and helpers that turn a scene blob
+(see blob.py) into the POD structs.  No compute happens here."""
+import ctypes as C
+
+import numpy as np
+
+NBINS = 30
+MT_N = 624
+
+PVOL_OK = 0
+PVOL_E_INVALID = -1
+PVOL_E_NO_DEVICE = -2
+PVOL_E_NO_SCENE = -3
+PVOL_E_NO_MEMORY = -4
+PVOL_E_UNSUPPORTED = -5
+PVOL_E_LIMIT = -6
+PVOL_E_SHOOT_FAILED = -7
+
+VOLUME_NONE, VOLUME_HOMOGENEOUS, VOLUME_GRID, VOLUME_RAINBOW = 0, 1, 2, 3
+LIGHT_POINT, LIGHT_SPOT, LIGHT_DISTANT = 0, 1, 2
+MATERIAL_MATTE, MATERIAL_GLASS = 0, 1
+OUT_SPECTRAL, OUT_XYZ = 0, 1
+
+
+class Spectrum(C.Structure):
+    _fields_ = [("c", C.c_float * NBINS)]
+
+
+class Volume(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("extent_min", C.c_float * 3), ("extent_max", C.c_float * 3),
+        ("world_to_volume", C.c_float * 16), ("volume_to_world", C.c_float * 16),
+        ("sigma_a", Spectrum), ("sigma_s", Spectrum), ("le", Spectrum),
+        ("g", C.c_float),
+        ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+        ("density", C.POINTER(C.c_float)),
+    ]
+
+
+class Light(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32),
+        ("pos", C.c_float * 3), ("dir", C.c_float * 3),
+        ("light_to_world", C.c_float * 16), ("world_to_light", C.c_float * 16),
+        ("intensity", Spectrum),
+        ("cos_total_width", C.c_float), ("cos_falloff_start", C.c_float),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("kd", Spectrum), ("kr", Spectrum), ("kt", Spectrum),
+                ("ior", C.c_float), ("vn", C.c_float)]
+
+
+class Triangle(C.Structure):
+    _fields_ = [("p", (C.c_float * 3) * 3), ("material", C.c_int32), ("flip_normal", C.c_int32)]
+
+
+class Scene(C.Structure):
+    _fields_ = [
+        ("volume", Volume),
+        ("n_lights", C.c_uint32), ("lights", C.POINTER(Light)),
+        ("n_triangles", C.c_uint32), ("triangles", C.POINTER(Triangle)),
+        ("n_materials", C.c_uint32), ("materials", C.POINTER(Material)),
+        ("world_min", C.c_float * 3), ("world_max", C.c_float * 3),
+        ("cie_x", Spectrum), ("cie_y", Spectrum), ("cie_z", Spectrum),
+        ("xyz_scale", C.c_float),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("step_size", C.c_float), ("n_used", C.c_int32), ("max_dist", C.c_float),
+        ("n_volume_photons", C.c_uint32), ("shooter_step_size", C.c_float),
+        ("max_photon_depth", C.c_int32), ("n_caustic_photons", C.c_uint32),
+        ("n_indirect_photons", C.c_uint32), ("final_gather", C.c_int32),
+        ("device", C.c_int32), ("grid_cell_scale", C.c_float), ("reserved", C.c_uint32 * 7),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_rays", C.c_uint64), ("n_steps", C.c_uint64), ("n_tested", C.c_uint64),
+                ("n_kept", C.c_uint64), ("n_lookups_lt10", C.c_uint64),
+                ("n_shadow_unoccluded", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+
+
+# numpy views of the two array-of-struct inputs (sizes checked against pvol.h in the tests)
+RAY_DTYPE = np.dtype([("o", "<f4", 3), ("mint", "<f4"), ("d", "<f4", 3), ("maxt", "<f4"),
+                      ("time", "<f4"), ("scatter_u", "<f4"), ("rng_skip", "<u4"), ("flags", "<u4")])
+STREAM_DTYPE = np.dtype([("seed", "<u4"), ("first_ray", "<u4"), ("n_rays", "<u4"), ("reserved", "<u4"),
+                         ("start_draw", "<u8"), ("end_draw", "<u8")])
+assert RAY_DTYPE.itemsize == 48 and STREAM_DTYPE.itemsize == 32
+
+
+def _spec(dst, src):
+    for i in range(NBINS):
+        dst.c[i] = float(src[i])
+
+
+def _fill(dst, src):
+    for i, v in enumerate(src):
+        dst[i] = float(v)
+
+
+class SceneHolder:
+    """Owns the ctypes arrays a pvol_scene points into."""
+
+    def __init__(self, b):
+        s = Scene()
+        v = s.volume
+        v.kind = int(b["vol.kind"][0])
+        _fill(v.extent_min, b["vol.extent"][:3])
+        _fill(v.extent_max, b["vol.extent"][3:])
+        _fill(v.world_to_volume, b["vol.w2v"])
+        _fill(v.volume_to_world, b["vol.v2w"])
+        _spec(v.sigma_a, b["vol.sigma_a"])
+        _spec(v.sigma_s, b["vol.sigma_s"])
+        _spec(v.le, b["vol.le"])
+        v.g = float(b["vol.g"][0])
+        v.nx, v.ny, v.nz = [int(x) for x in b["vol.dims"]]
+        self.density = None
+        if v.kind == VOLUME_GRID:
+            self.density = np.ascontiguousarray(b["vol.density"], dtype=np.float32)
+            assert self.density.size == v.nx * v.ny * v.nz
+            v.density = self.density.ctypes.data_as(C.POINTER(C.c_float))
+        nl = len(b["lights.kind"])
+        self.lights = (Light * max(nl, 1))()
+        for i in range(nl):
+            L = self.lights[i]
+            L.kind = int(b["lights.kind"][i])
+            _fill(L.pos, b["lights.pos"][3 * i:3 * i + 3])
+            _fill(L.dir, b["lights.dir"][3 * i:3 * i + 3])
+            _fill(L.light_to_world, b["lights.l2w"][16 * i:16 * i + 16])
+            _fill(L.world_to_light, b["lights.w2l"][16 * i:16 * i + 16])
+            _spec(L.intensity, b["lights.intensity"][NBINS * i:NBINS * (i + 1)])
+            L.cos_total_width = float(b["lights.cos"][2 * i])
+            L.cos_falloff_start = float(b["lights.cos"][2 * i + 1])
+        s.n_lights = nl
+        s.lights = C.cast(self.lights, C.POINTER(Light))
+        nt = len(b["tris.material"])
+        self.tris = (Triangle * max(nt, 1))()
+        for i in range(nt):
+            T = self.tris[i]
+            for k in range(3):
+                for c in range(3):
+                    T.p[k][c] = float(b["tris.p"][9 * i + 3 * k + c])
+            T.material = int(b["tris.material"][i])
+            T.flip_normal = int(b["tris.flip"][i])
+        s.n_triangles = nt
+        s.triangles = C.cast(self.tris, C.POINTER(Triangle))
+        nm = len(b["mats.kind"])
+        self.mats = (Material * max(nm, 1))()
+        for i in range(nm):
+            M = self.mats[i]
+            M.kind = int(b["mats.kind"][i])
+            _spec(M.kd, b["mats.kd"][NBINS * i:NBINS * (i + 1)])
+            _spec(M.kr, b["mats.kr"][NBINS * i:NBINS * (i + 1)])
+            _spec(M.kt, b["mats.kt"][NBINS * i:NBINS * (i + 1)])
+            M.ior = float(b["mats.ior"][i])
+            M.vn = float(b["mats.vn"][i])
+        s.n_materials = nm
+        s.materials = C.cast(self.mats, C.POINTER(Material))
+        _fill(s.world_min, b["world"][:3])
+        _fill(s.world_max, b["world"][3:])
+        _spec(s.cie_x, b["cie.x"])
+        _spec(s.cie_y, b["cie.y"])
+        _spec(s.cie_z, b["cie.z"])
+        s.xyz_scale = float(b["xyz_scale"][0])
+        self.scene = s
+        self.blob = b
+
+
+def params_from_blob(b, **over):
+    """pvol_params from a scene blob's params.f / params.i, with keyword overrides."""
+    p = Params()
+    p.step_size, p.max_dist, p.shooter_step_size = [float(x) for x in b["params.f"]]
+    (p.n_used, p.n_volume_photons, p.max_photon_depth, p.n_caustic_photons,
+     p.n_indirect_photons, p.final_gather) = [int(x) for x in b["params.i"]]
+    p.device = 0
+    p.grid_cell_scale = 0.0
+    for k, v in over.items():
+        setattr(p, k, v)
+    return p
+
+
+def make_rays(o, d, mint, maxt, scatter_u, time=0.0, rng_skip=0):
+    n = len(o)
+    r = np.zeros(n, dtype=RAY_DTYPE)
+    r["o"] = o
+    r["d"] = d
+    r["mint"] = mint
+    r["maxt"] = maxt
+    r["time"] = time
+    r["scatter_u"] = scatter_u
+    r["rng_skip"] = rng_skip
+    return r
+
+
+def make_streams(seeds, counts, start_draw=0):
+    s = np.zeros(len(seeds), dtype=STREAM_DTYPE)
+    s["seed"] = seeds
+    s["n_rays"] = counts
+    first = np.concatenate([[0], np.cumsum(counts)[:-1]]) if len(counts) else []
+    s["first_ray"] = first
+    s["start_draw"] = start_draw
+    return s

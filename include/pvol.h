@@ -1,0 +1,257 @@
+/*
+ * pvol.h -- C ABI of the MI355X-native volumetric photon-mapping hot path.
+ *
+ * This is the drop-in boundary for ONE path of the pbrt-v2 fork piwell/CS348B-pbrt:
+ *   core/photonshooter.cpp   (volume-photon shooting, PhotonShooter::Preprocess)
+ *   integrators/photonvolume.cpp (PhotonVolumeIntegrator::Li / Transmittance / LPhoton)
+ * Every entry point below names the reference interface (file:line under the reference
+ * tree) it replaces.  Plain pointers and sizes only; no C++/torch types.  All functions
+ * return PVOL_OK (0) or a negative pvol_status; they never abort, never print, and fail
+ * loudly (PVOL_E_NO_DEVICE) instead of falling back to a CPU path when no HIP device
+ * is usable.
+ *
+ * Conventions
+ *   - Spectra are 30 fp32 bins, 400..700 nm (core/spectrum.h:44-46).  The two tag floats
+ *     of the reference's 128-byte Spectrum are not carried: `lambda` is re-derived by
+ *     extractLambda() (core/spectrum.h:266-279), `intensity` is never read on the path.
+ *   - Matrices are row-major 4x4, m[r*4+c] == Transform::m.m[r][c] (core/transform.h).
+ *   - One MT19937 stream per render tile (renderers/samplerrenderer.cpp:73).  A batch
+ *     groups rays by stream; rays of one stream are consumed in array order, exactly as
+ *     the reference's tile loop consumes its RNG.
+ */
+#ifndef PVOL_H
+#define PVOL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVOL_NBINS 30
+#define PVOL_MT_N 624
+#define PVOL_ABI_VERSION 1
+
+typedef enum pvol_status {
+    PVOL_OK = 0,
+    PVOL_E_INVALID = -1,      /* bad argument / inconsistent sizes            */
+    PVOL_E_NO_DEVICE = -2,    /* no usable HIP device / HIP runtime error     */
+    PVOL_E_NO_SCENE = -3,     /* pvol_set_scene has not succeeded yet         */
+    PVOL_E_NO_MEMORY = -4,
+    PVOL_E_UNSUPPORTED = -5,  /* volume/light/material kind out of scope      */
+    PVOL_E_LIMIT = -6,        /* a ray needs more march steps than the kernel's LDS plan */
+    PVOL_E_SHOOT_FAILED = -7  /* "Unable to store enough photons" (photonshooter.cpp:285-299) */
+} pvol_status;
+
+typedef struct pvol_spectrum { float c[PVOL_NBINS]; } pvol_spectrum;
+
+/* ---- scene: a flattened POD copy of what the path reads from Scene ------------------ */
+
+typedef enum pvol_volume_kind {
+    PVOL_VOLUME_NONE = 0,
+    PVOL_VOLUME_HOMOGENEOUS = 1,  /* volumes/homogeneous.h:43-89 */
+    PVOL_VOLUME_GRID = 2,         /* volumes/volumegrid.{h,cpp}  */
+    PVOL_VOLUME_RAINBOW = 3       /* volumes/rainbow.{h,cpp} (homogeneous + rainbowReflection) */
+} pvol_volume_kind;
+
+typedef struct pvol_volume {
+    int32_t kind;
+    float extent_min[3], extent_max[3]; /* BBox extent in volume space                   */
+    float world_to_volume[16];          /* WorldToVolume.m                               */
+    float volume_to_world[16];          /* its inverse (WorldBound: homogeneous.h:57-59) */
+    pvol_spectrum sigma_a, sigma_s, le;
+    float g;                            /* HG asymmetry (core/volume.cpp:150-154)        */
+    int32_t nx, ny, nz;                 /* grid only                                     */
+    const float *density;               /* grid only: nx*ny*nz floats, x fastest (volumegrid.h:60-65) */
+} pvol_volume;
+
+typedef enum pvol_light_kind {
+    PVOL_LIGHT_POINT = 0,   /* lights/point.cpp   */
+    PVOL_LIGHT_SPOT = 1,    /* lights/spot.cpp    */
+    PVOL_LIGHT_DISTANT = 2  /* lights/distant.cpp */
+} pvol_light_kind;
+
+typedef struct pvol_light {
+    int32_t kind;
+    float pos[3];               /* lightPos (point, spot)                                 */
+    float dir[3];               /* lightDir, already normalised (distant)                 */
+    float light_to_world[16];
+    float world_to_light[16];
+    pvol_spectrum intensity;    /* I (point, spot) or L (distant)                         */
+    float cos_total_width;      /* spot.cpp:45                                            */
+    float cos_falloff_start;    /* spot.cpp:46                                            */
+} pvol_light;
+
+typedef enum pvol_material_kind {
+    PVOL_MATERIAL_MATTE = 0,  /* materials/matte.cpp:42-63, sigma == 0 => Lambertian      */
+    PVOL_MATERIAL_GLASS = 1   /* materials/glass.cpp:42-59 + dispersive SpecularTransmission */
+} pvol_material_kind;
+
+typedef struct pvol_material {
+    int32_t kind;
+    pvol_spectrum kd;   /* matte: Kd (already clamped >= 0)                               */
+    pvol_spectrum kr;   /* glass: Kr                                                      */
+    pvol_spectrum kt;   /* glass: Kt                                                      */
+    float ior;          /* glass "index"                                                  */
+    float vn;           /* glass Abbe number; > 0 => dispersive (materials/glass.h:57)    */
+} pvol_material;
+
+typedef struct pvol_triangle {
+    float p[3][3];          /* world-space vertices p1,p2,p3 (shapes/trianglemesh.cpp:70-71) */
+    int32_t material;       /* index into materials[]                                     */
+    int32_t flip_normal;    /* ReverseOrientation ^ TransformSwapsHandedness (core/diffgeom.cpp:52-53) */
+} pvol_triangle;
+
+typedef struct pvol_scene {
+    pvol_volume volume;
+    uint32_t n_lights;
+    const pvol_light *lights;
+    uint32_t n_triangles;
+    const pvol_triangle *triangles;
+    uint32_t n_materials;
+    const pvol_material *materials;
+    float world_min[3], world_max[3];  /* Scene::WorldBound(): geometry U volume (core/scene.cpp:59-60) */
+    pvol_spectrum cie_x, cie_y, cie_z; /* SampledSpectrum::X/Y/Z bin averages (core/spectrum.h:370-381) */
+    float xyz_scale;                   /* (700-400)/(CIE_Y_integral*30)  (core/spectrum.h:427-428)     */
+} pvol_scene;
+
+/* ---- integrator / shooter parameters (CreatePhotonVolumeIntegrator photonvolume.cpp:224-229,
+ *      CreatePhotonShooter photonshooter.cpp:529-548) ---------------------------------- */
+typedef struct pvol_params {
+    float step_size;            /* VolumeIntegrator "stepsize"  (default 1)               */
+    int32_t n_used;             /* VolumeIntegrator "nused"     (default 250)             */
+    float max_dist;             /* VolumeIntegrator "maxdist"   (default 0.1)             */
+    uint32_t n_volume_photons;  /* VolumeIntegrator "volumephotons" (default 0)           */
+    float shooter_step_size;    /* SurfaceIntegrator "stepsize" (default 0.1)             */
+    int32_t max_photon_depth;   /* SurfaceIntegrator "maxphotondepth" (default 5)         */
+    uint32_t n_caustic_photons; /* SurfaceIntegrator "causticphotons" (default 20000)     */
+    uint32_t n_indirect_photons;/* SurfaceIntegrator "indirectphotons" (default 10000)    */
+    int32_t final_gather;       /* SurfaceIntegrator "finalgather" (default true)         */
+    int32_t device;             /* HIP device ordinal                                     */
+    float grid_cell_scale;      /* 0 = auto; else photon-grid cell edge as a multiple of the auto choice */
+    uint32_t reserved[7];
+} pvol_params;
+
+/* ---- ray batches --------------------------------------------------------------------- */
+
+/* One camera ray handed to Li() (PhotonVolumeIntegrator::Li, photonvolume.cpp:112-222). */
+typedef struct pvol_ray {
+    float o[3];
+    float mint;
+    float d[3];
+    float maxt;
+    float time;
+    float scatter_u;   /* sample->oneD[scatterSampleOffset][0]  (photonvolume.cpp:135)   */
+    uint32_t rng_skip; /* draws of this ray's stream the CALLER consumed since the previous
+                          ray of the stream (sampler + surface integrator), skipped before Li */
+    uint32_t flags;    /* reserved, 0                                                     */
+} pvol_ray;            /* 48 bytes                                                        */
+
+/* One MT19937 stream == one render tile (samplerrenderer.cpp:73 `RNG rng(taskNum)`).     */
+typedef struct pvol_stream {
+    uint32_t seed;        /* RNG(seed)                                                    */
+    uint32_t first_ray;   /* rays [first_ray, first_ray+n_rays) of the batch, in order    */
+    uint32_t n_rays;
+    uint32_t reserved;
+    uint64_t start_draw;  /* RandomUInt() calls already made on this stream before the batch */
+    uint64_t end_draw;    /* OUT: calls made after the last ray of the batch               */
+} pvol_stream;            /* 32 bytes                                                     */
+
+typedef enum pvol_output_kind {
+    PVOL_OUT_SPECTRAL = 0, /* per ray: Lv[30] then T[30]          (60 floats)             */
+    PVOL_OUT_XYZ = 1       /* per ray: Lv as X,Y,Z then T.y()     (4 floats)              */
+} pvol_output_kind;
+
+typedef struct pvol_stats {
+    uint64_t n_rays;           /* Li() calls                                              */
+    uint64_t n_steps;          /* march steps == photon lookups (non-rainbow)             */
+    uint64_t n_tested;         /* photons distance-tested by the gather                   */
+    uint64_t n_kept;           /* photons that entered a flux sum                         */
+    uint64_t n_lookups_lt10;   /* lookups that found < 10 photons (photonvolume.cpp:83)   */
+    uint64_t n_shadow_unoccluded;
+    uint64_t reserved[2];
+} pvol_stats;
+
+typedef struct pvol_ctx pvol_ctx;
+
+/* Version of this ABI (PVOL_ABI_VERSION). */
+int pvol_abi_version(void);
+/* Static string for a pvol_status. */
+const char *pvol_strerror(int status);
+/* Number of usable HIP devices (0 when none; never a CPU fallback). */
+int pvol_device_count(void);
+
+/* Fill *p with the reference defaults (photonvolume.cpp:224-229, photonshooter.cpp:529-548). */
+void pvol_default_params(pvol_params *p);
+
+/* Replaces CreatePhotonVolumeIntegrator + CreatePhotonShooter (photonvolume.cpp:224-229,
+ * photonshooter.cpp:529-548; constructed from core/api.cpp:572-586,1225-1230). */
+int pvol_create(const pvol_params *params, pvol_ctx **out);
+/* Replaces ~PhotonShooter / ~PhotonVolumeIntegrator (photonshooter.cpp:423-430). */
+void pvol_destroy(pvol_ctx *ctx);
+
+/* Copies the flattened scene to the device (what Li()/followPhoton read through
+ * `const Scene *`: core/scene.h:42-73).  May be called again to replace the scene. */
+int pvol_set_scene(pvol_ctx *ctx, const pvol_scene *scene);
+
+/* Installs a volume photon map computed elsewhere (e.g. by the reference's own
+ * PhotonShooter) and builds the device search structure; replaces
+ * `volumeMap = new KdTree<Photon>(volumePhotons)` (photonshooter.cpp:502-503).
+ * p, wi: 3*n floats (xyz interleaved); alpha: 30*n floats.  n == 0 clears the map
+ * (a NULL map is legal, photonvolume.cpp:69). */
+int pvol_upload_photons(pvol_ctx *ctx, const float *p, const float *wi,
+                        const float *alpha, uint32_t n);
+
+/* Replaces PhotonShooter::Preprocess (photonshooter.cpp:457-526): shoots volume photons
+ * on the device with `n_tasks` virtual PhotonShootingTasks (task t uses RNG(31*t) and its
+ * own Halton permutation, photonshooter.cpp:235,243), merges them in task order per block
+ * round (photonshooter.cpp:280-351) and builds the search structure. */
+int pvol_preprocess(pvol_ctx *ctx, uint32_t n_tasks);
+
+/* Number of photons in the current volume map. */
+int pvol_photon_count(pvol_ctx *ctx, uint32_t *n);
+/* Copies the current map back (same layout as pvol_upload_photons); capacity in photons. */
+int pvol_download_photons(pvol_ctx *ctx, float *p, float *wi, float *alpha, uint32_t capacity);
+
+/* Replaces PhotonVolumeIntegrator::Li (photonvolume.cpp:112-222) for a batch of rays
+ * grouped into MT19937 streams.  Host pointers; `out` has n_rays*60 (SPECTRAL) or
+ * n_rays*4 (XYZ) floats; `draws` (optional) receives per ray the number of RandomUInt
+ * calls Li() made (4+6n+n+r+u).  streams[i].end_draw is written. */
+int pvol_li_batch(pvol_ctx *ctx, const pvol_ray *rays, uint32_t n_rays,
+                  pvol_stream *streams, uint32_t n_streams,
+                  int output_kind, float *out, uint32_t *draws);
+
+/* Same, all pointers are DEVICE pointers and the work is enqueued on `hip_stream`
+ * (a hipStream_t, NULL = default stream) without synchronising. */
+int pvol_li_batch_device(pvol_ctx *ctx, const pvol_ray *d_rays, uint32_t n_rays,
+                         pvol_stream *d_streams, uint32_t n_streams,
+                         int output_kind, float *d_out, uint32_t *d_draws,
+                         void *hip_stream);
+
+/* Single call with the caller's live RNG (the per-sample shim behind
+ * VolumeIntegrator::Li): mt[624] / *mti are core/rng.h:57-58 narrowed to 32 bits and are
+ * advanced exactly as the reference would advance them.  Lv, T: 30 floats each. */
+int pvol_li(pvol_ctx *ctx, const pvol_ray *ray, uint32_t *mt, int32_t *mti,
+            float *Lv, float *T);
+
+/* Replaces PhotonVolumeIntegrator::Transmittance with sample == NULL
+ * (photonvolume.cpp:15-30): step = 4*stepSize, offset = one RandomFloat per ray.
+ * Rays are grouped into streams like pvol_li_batch; out: 30 floats per ray. */
+int pvol_transmittance_batch(pvol_ctx *ctx, const pvol_ray *rays, uint32_t n_rays,
+                             pvol_stream *streams, uint32_t n_streams, float *out);
+
+/* Work counters accumulated since the last reset (feeds the algorithmic-bytes formula
+ * B_lookup = 20*V + 132*K of SURVEY 8(d)). */
+int pvol_get_stats(pvol_ctx *ctx, pvol_stats *out, int reset);
+/* Enable/disable counter collection in the kernels (off by default: atomics cost time). */
+int pvol_enable_stats(pvol_ctx *ctx, int on);
+
+/* Average device time of the dominant (march+gather) kernel over the launches since
+ * the last reset, measured with HIP events on the launch stream. */
+int pvol_kernel_time_ms(pvol_ctx *ctx, double *avg_ms, uint64_t *launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVOL_H */

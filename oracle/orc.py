@@ -1,0 +1,156 @@
+"""ctypes binding of oracle/liborc.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_pkg = importlib.import_module("cs348b-pbrt_amd")
+abi = _pkg.abi
+
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def build():
+    """(Re)build liborc.so (and oracle/_ref when the reference tree is present)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(abi.Params), C.POINTER(abi.Scene)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32]
+        L.orc_photon_count.argtypes = [C.c_void_p]
+        L.orc_photon_count.restype = C.c_uint32
+        L.orc_get_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32]
+        L.orc_li_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, _f32p, _u32p, C.c_int]
+        L.orc_transmittance_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, _f32p]
+        L.orc_get_counters.argtypes = [C.c_void_p, _u64p, C.c_int]
+        L.orc_lphoton_batch.argtypes = [C.c_void_p, _f32p, _f32p, C.c_uint32, _f32p]
+        L.orc_shoot.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.orc_get_shoot_stats.argtypes = [C.c_void_p, _u64p]
+        L.orc_rng_draws.argtypes = [C.c_uint32, C.c_uint32, _u32p]
+        L.orc_rng_floats.argtypes = [C.c_uint32, C.c_uint32, _f32p]
+        L.orc_halton.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
+        L.orc_ld_shuffle_1d.argtypes = [C.c_uint32, C.c_int, C.c_int, _f32p]
+        L.orc_ld_shuffle_1d.restype = C.c_uint32
+        L.orc_ld_shuffle_2d.argtypes = [C.c_uint32, C.c_int, C.c_int, _f32p]
+        L.orc_ld_shuffle_2d.restype = C.c_uint32
+        L.orc_spec_y.argtypes = [C.c_void_p, _f32p]
+        L.orc_spec_y.restype = C.c_float
+        L.orc_spec_xyz.argtypes = [C.c_void_p, _f32p, _f32p]
+        L.orc_light_powers.argtypes = [C.c_void_p, _f32p]
+        L.orc_light_emit.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, _f32p]
+        L.orc_light_sample.argtypes = [C.c_void_p, C.c_uint32, _f32p, _f32p]
+        L.orc_intersect.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float, _f32p]
+        L.orc_intersect_p.argtypes = [C.c_void_p, _f32p, _f32p, C.c_float, C.c_float]
+        L.orc_bsdf_sample.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, C.c_float, C.c_float, C.c_float, _f32p, _f32p, _f32p]
+        L.orc_volume_query.argtypes = [C.c_void_p, _f32p, _f32p]
+        L.orc_rainbow.argtypes = [_f32p, _f32p, _f32p, _f32p]
+        L.orc_mc_samples.argtypes = [C.c_float, C.c_float, _f32p]
+        L.orc_phase.argtypes = [C.c_float, _f32p]
+        _lib = L
+    return _lib
+
+
+COUNTER_NAMES = ["n_rays", "n_steps", "n_lookups", "n_nodes_visited", "n_heap_offers", "n_kept",
+                 "n_lookups_lt10", "n_shadow_unoccluded", "n_density_evals", "n_draws"]
+SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
+                    "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
+
+
+class Oracle:
+    """CPU restatement of the hot path bound to one scene + parameter set."""
+
+    def __init__(self, scene_holder, params):
+        self._holder = scene_holder
+        self.params = params
+        self._h = lib().orc_create(C.byref(params), C.byref(scene_holder.scene))
+
+    def close(self):
+        if self._h:
+            lib().orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_photons(self, p, wi, alpha):
+        p = np.ascontiguousarray(p, np.float32).reshape(-1)
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1)
+        alpha = np.ascontiguousarray(alpha, np.float32).reshape(-1)
+        n = p.size // 3
+        assert wi.size == 3 * n and alpha.size == 30 * n
+        lib().orc_set_photons(self._h, _p(p, _f32p), _p(wi, _f32p), _p(alpha, _f32p), n)
+
+    def photon_count(self):
+        return int(lib().orc_photon_count(self._h))
+
+    def get_photons(self):
+        n = self.photon_count()
+        p = np.zeros((n, 3), np.float32)
+        wi = np.zeros((n, 3), np.float32)
+        alpha = np.zeros((n, 30), np.float32)
+        lib().orc_get_photons(self._h, _p(p, _f32p), _p(wi, _f32p), _p(alpha, _f32p), n)
+        return p, wi, alpha
+
+    def li_batch(self, rays, streams, output_kind=abi.OUT_SPECTRAL, n_threads=1):
+        n = len(rays)
+        width = 60 if output_kind == abi.OUT_SPECTRAL else 4
+        out = np.zeros((n, width), np.float32)
+        draws = np.zeros(n, np.uint32)
+        rays = np.ascontiguousarray(rays)
+        lib().orc_li_batch(self._h, rays.ctypes.data, n, streams.ctypes.data, len(streams), output_kind,
+                           _p(out, _f32p), _p(draws, _u32p), n_threads)
+        return out, draws
+
+    def transmittance_batch(self, rays, streams):
+        n = len(rays)
+        out = np.zeros((n, 30), np.float32)
+        rays = np.ascontiguousarray(rays)
+        lib().orc_transmittance_batch(self._h, rays.ctypes.data, n, streams.ctypes.data, len(streams), _p(out, _f32p))
+        return out
+
+    def lphoton_batch(self, pts, w):
+        pts = np.ascontiguousarray(pts, np.float32)
+        w = np.ascontiguousarray(w, np.float32)
+        out = np.zeros((len(pts), 30), np.float32)
+        lib().orc_lphoton_batch(self._h, _p(pts, _f32p), _p(w, _f32p), len(pts), _p(out, _f32p))
+        return out
+
+    def counters(self, reset=False):
+        v = np.zeros(10, np.uint64)
+        lib().orc_get_counters(self._h, _p(v, _u64p), int(reset))
+        return dict(zip(COUNTER_NAMES, [int(x) for x in v]))
+
+    def shoot(self, n_tasks=1, n_threads=1):
+        return lib().orc_shoot(self._h, n_tasks, n_threads)
+
+    def shoot_stats(self):
+        v = np.zeros(12, np.uint64)
+        lib().orc_get_shoot_stats(self._h, _p(v, _u64p))
+        return dict(zip(SHOOT_STAT_NAMES, [int(x) for x in v]))

@@ -1,0 +1,404 @@
+// oracle/orc_shooter.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE (see orc_core.h).
+//
+// CPU restatement of core/photonshooter.cpp: PhotonShootingTask::Run / followPhoton and the
+// two BSDFs photon paths meet in the scoped scenes (Lambertian; specular dielectric
+// transmission/reflection with the fork's Cauchy dispersion).  Only the VOLUME photon store is
+// kept; caustic / direct / indirect / radiance photons are counted because their counts steer
+// control flow and RNG consumption (photonshooter.cpp:148-189,304-351).
+//
+// PINNING NOTE: the reference's own shooter cannot be linked here (it needs core/parallel.cpp,
+// which does not compile in this image: <sys/sysctl.h> is absent).  followPhoton as a whole is
+// therefore "parity unpinned"; its building blocks (lights, BSDF sampling, closest hit,
+// transmittance, Halton, RNG) are pinned individually against the reference's objects.
+#ifndef ORC_SHOOTER_H
+#define ORC_SHOOTER_H
+
+#include <atomic>
+#include <thread>
+#include "orc_integrator.h"
+
+namespace orc {
+
+enum {  // core/reflection.h:107-121
+    BSDF_REFLECTION = 1 << 0, BSDF_TRANSMISSION = 1 << 1, BSDF_DIFFUSE = 1 << 2, BSDF_GLOSSY = 1 << 3, BSDF_SPECULAR = 1 << 4
+};
+
+struct ShootStats {
+    uint64_t paths, follow_calls, no_hit, march_steps, interactions, absorbed, stored_volume, stored_caustic,
+        stored_direct, stored_indirect, split_children, nshot;
+    ShootStats() { memset(this, 0, sizeof(*this)); }
+};
+
+// core/reflection.cpp:60-67 with scalar indices broadcast to every bin
+inline Spec fr_diel(float cosi, float cost, float etai, float etat) {
+    Spec ei = spec_const(etai), et = spec_const(etat);
+    Spec Rparl = ((et * cosi) - (ei * cost)) / ((et * cosi) + (ei * cost));
+    Spec Rperp = ((ei * cosi) - (et * cost)) / ((ei * cosi) + (et * cost));
+    return (Rparl * Rparl + Rperp * Rperp) / 2.f;
+}
+// core/reflection.cpp:115-135
+inline Spec fresnel_dielectric(float cosi, float eta_i, float eta_t) {
+    cosi = cosi < -1.f ? -1.f : (cosi > 1.f ? 1.f : cosi);
+    bool entering = cosi > 0.;
+    float ei = eta_i, et = eta_t;
+    if (!entering) std::swap(ei, et);
+    float sint = ei / et * sqrtf(std::max(0.f, 1.f - cosi * cosi));
+    if (sint >= 1.) return spec_const(1.f);
+    float cost = sqrtf(std::max(0.f, 1.f - sint * sint));
+    return fr_diel(fabsf(cosi), cost, ei, et);
+}
+
+struct BxdfList {
+    int n;
+    int type[2];  // BxDFType of each component, in Add() order (glass.cpp:52-57, matte.cpp:55-60)
+};
+inline BxdfList material_bxdfs(const Material &m) {
+    BxdfList b; b.n = 0; b.type[0] = b.type[1] = 0;
+    if (m.kind == PVOL_MATERIAL_MATTE) {
+        if (!is_black(m.kd)) b.type[b.n++] = BSDF_REFLECTION | BSDF_DIFFUSE;
+    } else {
+        if (!is_black(m.kr)) b.type[b.n++] = BSDF_REFLECTION | BSDF_SPECULAR;
+        if (!is_black(m.kt)) b.type[b.n++] = BSDF_TRANSMISSION | BSDF_SPECULAR;
+    }
+    return b;
+}
+inline int num_components(const BxdfList &b, int flags) {  // reflection.h:534-539
+    int num = 0;
+    for (int i = 0; i < b.n; ++i) if ((b.type[i] & flags) == b.type[i]) ++num;
+    return num;
+}
+
+// BSDF::Sample_f with flags == BSDF_ALL (core/reflection.cpp:534-598) over the shading frame
+// of core/reflection.cpp:619-627 (sn = normalize(dpdu), tn = nn x sn; ng == nn for flat triangles).
+// `alpha` is the photon weight handed to SpecularTransmission::Sample_f for dispersion
+// (reflection.cpp:147-182).  Returns f; *flags = sampled BxDFType (0 when nothing was sampled).
+inline Spec bsdf_sample_f(const Scene &sc, int tri, V3 dpdu, V3 nn, V3 woW, V3 *wiW, float u0, float u1, float ucomp,
+                          float *pdf, int *sampledType, const Spec &alpha) {
+    const Material &m = sc.mats[sc.tris[tri].material];
+    BxdfList bl = material_bxdfs(m);
+    const int flagsAll = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR;
+    int matchingComps = num_components(bl, flagsAll);
+    if (matchingComps == 0) { *pdf = 0.f; *sampledType = 0; return spec_const(0.f); }
+    int which = std::min((int)floorf(ucomp * matchingComps), matchingComps - 1);
+    int type = bl.type[which];
+    V3 sn = normalize(dpdu);
+    V3 tn = cross(nn, sn);
+    V3 wo = v3(dot(woW, sn), dot(woW, tn), dot(woW, nn));
+    V3 wi;
+    *pdf = 0.f;
+    Spec f;
+    if (type == (BSDF_REFLECTION | BSDF_DIFFUSE)) {
+        // BxDF::Sample_f (reflection.cpp:323-330), Lambertian::f (:185-187), BxDF::Pdf (:333-335)
+        wi = cosine_sample_hemisphere(u0, u1);
+        if (wo.z < 0.) wi.z *= -1.f;
+        *pdf = (wo.z * wi.z > 0.f) ? fabsf(wi.z) * kInvPi : 0.f;
+        f = m.kd * kInvPi;
+    } else if (type == (BSDF_REFLECTION | BSDF_SPECULAR)) {
+        // SpecularReflection::Sample_f (reflection.cpp:138-144) with FresnelDielectric(1, ior)
+        wi = v3(-wo.x, -wo.y, wo.z);
+        *pdf = 1.f;
+        f = fresnel_dielectric(wo.z, 1.f, m.ior) * m.kr / fabsf(wi.z);
+    } else {
+        // SpecularTransmission::Sample_f (reflection.cpp:147-182), etai = 1, etat = ior
+        bool entering = wo.z > 0.;
+        float ei = 1.f, et = m.ior;
+        int lambda;
+        if ((lambda = extract_lambda(alpha)) > 0 && m.vn > 0.f) {
+            float l = lambda / 1000.f;
+            float B = ((et - 1) / m.vn) * 0.52345;   // double product rounded to float
+            float A = et - (B / 0.34522792);          // double quotient rounded to float
+            et = A + B / pow(l, 2);                   // pow in double (reflection.cpp:161)
+        }
+        if (!entering) std::swap(ei, et);
+        float sini2 = std::max(0.f, 1.f - wo.z * wo.z);
+        float eta = ei / et;
+        float sint2 = eta * eta * sini2;
+        if (sint2 >= 1.) { *pdf = 0.f; *sampledType = 0; return spec_const(0.f); }  // f = 0, pdf stays 0 (:173 -> :566-571)
+        float cost = sqrtf(std::max(0.f, 1.f - sint2));
+        if (entering) cost = -cost;
+        float sintOverSini = eta;
+        wi = v3(sintOverSini * -wo.x, sintOverSini * -wo.y, cost);
+        *pdf = 1.f;
+        Spec F = fresnel_dielectric(wo.z, 1.f, m.ior);  // the Fresnel term keeps the undispersed index
+        f = (spec_const(1.f) - F) * m.kt / fabsf(wi.z);
+    }
+    if (*pdf == 0.f) { *sampledType = 0; return spec_const(0.f); }
+    *sampledType = type;
+    *wiW = v3(sn.x * wi.x + tn.x * wi.y + nn.x * wi.z, sn.y * wi.x + tn.y * wi.y + nn.y * wi.z, sn.z * wi.x + tn.z * wi.y + nn.z * wi.z);
+    // reflection.cpp:575-580: other matching components add their Pdf for non-specular samples;
+    // specular components have Pdf == 0 (reflection.h:343-345), so only the division remains.
+    if (matchingComps > 1) *pdf /= matchingComps;
+    if (!(type & BSDF_SPECULAR)) {
+        // reflection.cpp:583-592: re-evaluate f over components on the sampled side
+        int fl = flagsAll;
+        if (dot(*wiW, nn) * dot(woW, nn) > 0) fl &= ~BSDF_TRANSMISSION; else fl &= ~BSDF_REFLECTION;
+        f = spec_const(0.f);
+        for (int i = 0; i < bl.n; ++i)
+            if ((bl.type[i] & fl) == bl.type[i]) {
+                if (bl.type[i] == (BSDF_REFLECTION | BSDF_DIFFUSE)) f += m.kd * kInvPi;
+                // specular components return f() == 0 (reflection.h:339-341)
+            }
+    }
+    return f;
+}
+
+struct ShootTask {
+    // PhotonShootingTask::Run locals (photonshooter.cpp:233-244)
+    Rng rng;
+    PermutedHalton halton;
+    uint32_t totalPaths;
+    bool causticDone, indirectDone, volumeDone, finished;
+    std::vector<Photon> localVolume;
+    uint32_t localCaustic, localDirect, localIndirect;
+    ShootStats st;
+    ShootTask(int taskNum, const pvol_params &p)
+        : rng(31u * (uint32_t)taskNum), halton(6, rng), totalPaths(0), finished(false), localCaustic(0), localDirect(0), localIndirect(0) {
+        causticDone = (p.n_caustic_photons == 0);
+        indirectDone = (p.n_indirect_photons == 0);
+        volumeDone = (p.n_volume_photons == 0);
+    }
+};
+
+struct ShootShared {
+    const Scene *scene;
+    const pvol_params *params;
+    Integrator integ;  // renderer->Transmittance forwards to the volume integrator (samplerrenderer.cpp:253-258)
+    std::vector<float> lightFunc, lightCdf;  // Distribution1D (montecarlo.h:54-76)
+    float lightFuncInt;
+};
+
+// PhotonShootingTask::followPhoton, photonshooter.cpp:47-229.  `lambdaTag` is Spectrum::lambda of
+// `alpha` (spectrum.h:323), which survives in-place *= and /= and is re-derived on assignment from
+// an arithmetic expression (spectrum.h:339-344).
+inline void follow_photon(const ShootShared &S, ShootTask &T, Ray photonRay, Hit photonIsect, Spec alpha, float lambdaTag,
+                          int nIntersections, bool specularPath) {
+    const Scene &sc = *S.scene;
+    const float stepSize = S.params->shooter_step_size;
+    ++T.st.follow_calls;
+    if (!scene_intersect(sc, &photonRay, &photonIsect)) { ++T.st.no_hit; return; }
+    ++nIntersections;
+    float t0, t1;
+    float len = length(photonRay.d);
+    if (len == 0.f) return;
+    Ray rn = make_ray(photonRay.o, photonRay.d / len, photonRay.mint * len, photonRay.maxt * len, 0.f);  // time defaults to 0 (:60)
+    if (!vol_intersect(sc.vol, rn, &t0, &t1)) { t0 = 1.0; t1 = 0.0; }
+    t0 += T.rng.random_float() * stepSize;
+    float t_i = t0;
+    float xi = T.rng.random_float();
+    bool interaction = false;
+    while (t0 < t1) {
+        ++T.st.march_steps;
+        Ray shortRay = make_ray(photonRay.o, rn.d, t_i, t0, 0.f);
+        Spec tr = transmittance(S.integ, shortRay, T.rng, 0);
+        if (xi > spec_y(sc.cie, tr)) { interaction = true; break; }
+        t0 += stepSize;
+    }
+    if (interaction) {
+        ++T.st.interactions;
+        V3 interactPt = ray_at(rn, t0);
+        Spec sig_s = vol_sigma_s(sc.vol, interactPt);
+        Spec sig_a = vol_sigma_a(sc.vol, interactPt);
+        bool scatter = (T.rng.random_float() > spec_y(sc.cie, sig_s) / (spec_y(sc.cie, sig_a) + spec_y(sc.cie, sig_s)));
+        if (!scatter) { ++T.st.absorbed; return; }
+        if (scatter && !T.volumeDone) {
+            if (nIntersections > 1) {
+                Photon ph; ph.p = interactPt; ph.alpha = alpha; ph.wi = rn.d;
+                T.localVolume.push_back(ph);
+            }
+            float u1 = T.rng.random_float();
+            float u2 = T.rng.random_float();
+            V3 direction = uniform_sample_sphere(u1, u2);
+            float pdf = 1.f / (4.f * kPi);
+            float ref = vol_phase(sc.vol, interactPt, rn.d, direction);
+            if (ref == 0.f || pdf == 0.f) return;  // Spectrum(ref).IsBlack()
+            alpha *= spec_const(ref);
+            alpha /= pdf;
+            photonRay = make_ray(interactPt, direction, 0.f, kInfinity, 0.f);
+            follow_photon(S, T, photonRay, photonIsect, alpha, lambdaTag, nIntersections, specularPath);
+        }
+    }
+
+    // Handle photon/surface intersection (:131-189) -- with the possibly reassigned photonRay
+    alpha *= transmittance(S.integ, photonRay, T.rng, 0);
+    const Material &mat = sc.mats[sc.tris[photonIsect.tri].material];
+    BxdfList bl = material_bxdfs(mat);
+    const int specularType = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
+    const int allTransmission = BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR;
+    bool hasNonSpecular = (bl.n > num_components(bl, specularType));
+    bool hasTransmission = num_components(bl, allTransmission) > 0;
+    Spec children[NB];
+    float childTag[NB];
+    int nChildren = 0;
+    bool dispersive = (mat.kind == PVOL_MATERIAL_GLASS && mat.vn > 0.f);  // glass.h:57; Primitive::dispersive
+    if (hasTransmission && lambdaTag < 0 && dispersive) {
+        // SampledSpectrum::splitSpectrum, core/spectrum.cpp:100-111
+        float spectralStep = (700 - 400) / (float)(NB - 1);
+        for (int i = 0; i < NB; ++i) {
+            if (alpha.c[i] != 0.f) {
+                children[nChildren] = spec_const(0.f);
+                children[nChildren].c[i] = alpha.c[i];
+                childTag[nChildren] = 400 + i * spectralStep;
+                ++nChildren;
+            }
+        }
+        T.st.split_children += nChildren;
+    } else {
+        children[0] = alpha; childTag[0] = lambdaTag; nChildren = 1;
+    }
+    V3 wo = -photonRay.d;
+    if (hasNonSpecular) {
+        bool deposited = false;
+        if (specularPath && nIntersections > 1) {
+            if (!T.causticDone) { deposited = true; ++T.localCaustic; }
+        } else {
+            if (nIntersections == 1 && !T.indirectDone && S.params->final_gather) { deposited = true; ++T.localDirect; }
+            else if (nIntersections > 1 && !T.indirectDone) { deposited = true; ++T.localIndirect; }
+        }
+        if (deposited && S.params->final_gather && T.rng.random_float() < .125f) {
+            // two BSDF::rho(rng, ...) calls = 2 x 2 x StratifiedSample2D(6x6) = 288 RandomFloat (reflection.cpp:647-658)
+            T.rng.skip(288);
+        }
+    }
+    if (nIntersections >= S.params->max_photon_depth) return;
+
+    for (int i = 0; i < nChildren; ++i) {
+        alpha = children[i];
+        lambdaTag = childTag[i];
+        V3 wi; float pdf; int flags;
+        float ud0 = T.rng.random_float(), ud1 = T.rng.random_float(), uc = T.rng.random_float();  // BSDFSample(rng), reflection.h:135-139
+        Spec fr = bsdf_sample_f(sc, photonIsect.tri, photonIsect.dpdu, photonIsect.nn, wo, &wi, ud0, ud1, uc, &pdf, &flags, alpha);
+        if (is_black(fr) || pdf == 0.f) continue;
+        Spec anew = alpha * fr * fabsf(dot(wi, photonIsect.nn)) / pdf;
+        float continueProb = std::min(1.f, spec_y(sc.cie, anew) / spec_y(sc.cie, alpha));
+        if (T.rng.random_float() > continueProb) continue;
+        alpha = anew / continueProb;
+        lambdaTag = (float)extract_lambda(alpha);
+        specularPath &= ((flags & BSDF_SPECULAR) != 0);
+        if (T.indirectDone && !specularPath) continue;
+        photonRay = make_ray(photonIsect.p, wi, photonIsect.rayEpsilon, kInfinity, 0.f);
+        follow_photon(S, T, photonRay, photonIsect, alpha, lambdaTag, nIntersections, specularPath);
+    }
+}
+
+// One block of PhotonShootingTask::Run's loop body (photonshooter.cpp:246-277)
+inline void shoot_block(const ShootShared &S, ShootTask &T) {
+    const Scene &sc = *S.scene;
+    const uint32_t blockSize = 4096;
+    int nLights = (int)sc.lights.size();
+    for (uint32_t i = 0; i < blockSize; ++i) {
+        float u[6];
+        T.halton.sample(++T.totalPaths, u);
+        ++T.st.paths;
+        // Distribution1D::SampleDiscrete, montecarlo.h:99-107
+        const float *cdf = &S.lightCdf[0];
+        const float *ptr = std::upper_bound(cdf, cdf + nLights + 1, u[0]);
+        int lightNum = std::max(0, int(ptr - cdf - 1));
+        float lightPdf = S.lightFunc[lightNum] / (S.lightFuncInt * nLights);
+        Ray photonRay; V3 Nl; float pdf;
+        Spec Le = light_sample_emit(sc, sc.lights[lightNum], u[1], u[2], 0.f, &photonRay, &Nl, &pdf);
+        if (pdf == 0.f || is_black(Le)) continue;
+        Spec alpha = (fabsf(dot(Nl, photonRay.d)) * Le) / (pdf * lightPdf);
+        if (!is_black(alpha)) {
+            Hit isect; memset(&isect, 0, sizeof(isect));
+            follow_photon(S, T, photonRay, isect, alpha, (float)extract_lambda(alpha), 0, true);
+        }
+    }
+}
+
+// PhotonShooter::Preprocess (photonshooter.cpp:457-526) with `nTasks` virtual tasks.  Tasks
+// advance in lock-step rounds (one 4096-path block each) and merge in task order, which is the
+// reference's mutex-ordered merge (photonshooter.cpp:280-351) made deterministic; nTasks == 1
+// reproduces --ncores 1 exactly.
+inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t nTasks, int nThreads,
+                         std::vector<Photon> *volumeOut, ShootStats *stats) {
+    volumeOut->clear();
+    *stats = ShootStats();
+    if (scene.lights.empty()) return 0;  // photonshooter.cpp:459
+    ShootShared S;
+    S.scene = &scene;
+    S.params = &params;
+    S.integ.stepSize = params.step_size;
+    S.integ.maxDist = params.max_dist;
+    S.integ.maxDistSquared = params.max_dist * params.max_dist;
+    S.integ.nUsed = params.n_used;
+    S.integ.scene = &scene;
+    S.integ.volumeMap = 0;
+    // ComputeLightSamplingCDF (core/integrator.cpp:261-268) + Distribution1D ctor (montecarlo.h:56-76)
+    int n = (int)scene.lights.size();
+    S.lightFunc.resize(n);
+    for (int i = 0; i < n; ++i) S.lightFunc[i] = spec_y(scene.cie, light_power(scene, scene.lights[i]));
+    S.lightCdf.resize(n + 1);
+    S.lightCdf[0] = 0.;
+    for (int i = 1; i < n + 1; ++i) S.lightCdf[i] = S.lightCdf[i - 1] + S.lightFunc[i - 1] / n;
+    S.lightFuncInt = S.lightCdf[n];
+    if (S.lightFuncInt == 0.f) { for (int i = 1; i < n + 1; ++i) S.lightCdf[i] = float(i) / float(n); }
+    else { for (int i = 1; i < n + 1; ++i) S.lightCdf[i] /= S.lightFuncInt; }
+
+    std::vector<ShootTask *> tasks;
+    for (uint32_t t = 0; t < nTasks; ++t) tasks.push_back(new ShootTask((int)t, params));
+    uint32_t nshot = 0;
+    uint64_t nCaustic = 0, nIndirect = 0, nDirect = 0;
+    bool abortTasks = false;
+    int rc = 0;
+    const uint32_t blockSize = 4096;
+    auto unsuccessful = [](uint32_t needed, uint64_t found, uint32_t shot) {  // photonshooter.cpp:37-39
+        return (found < needed && (found == 0 || found < shot / 1024));
+    };
+    for (;;) {
+        std::vector<ShootTask *> live;
+        for (auto *t : tasks) if (!t->finished) live.push_back(t);
+        if (live.empty()) break;
+        // run one block per live task (in parallel; tasks share nothing while shooting)
+        if (nThreads <= 1 || live.size() == 1) { for (auto *t : live) shoot_block(S, *t); }
+        else {
+            std::atomic<size_t> next(0);
+            std::vector<std::thread> th;
+            for (int k = 0; k < nThreads; ++k)
+                th.emplace_back([&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= live.size()) break; shoot_block(S, *live[i]); } });
+            for (auto &x : th) x.join();
+        }
+        // merge in task order (photonshooter.cpp:280-351)
+        for (auto *t : live) {
+            if (abortTasks) { t->finished = true; continue; }
+            if (nshot > 500000 && (unsuccessful(params.n_caustic_photons, nCaustic, blockSize) ||
+                                   unsuccessful(params.n_indirect_photons, nIndirect, blockSize) ||
+                                   unsuccessful(params.n_volume_photons, volumeOut->size(), blockSize))) {
+                volumeOut->clear(); nCaustic = nIndirect = 0;
+                abortTasks = true; t->finished = true; rc = PVOL_E_SHOOT_FAILED;
+                continue;
+            }
+            nshot += blockSize;
+            if (!t->indirectDone) {
+                nIndirect += t->localIndirect; t->localIndirect = 0;
+                if (nIndirect >= params.n_indirect_photons) t->indirectDone = true;
+                nDirect += t->localDirect; t->localDirect = 0;
+            }
+            if (!t->causticDone) {
+                nCaustic += t->localCaustic; t->localCaustic = 0;
+                if (nCaustic >= params.n_caustic_photons) t->causticDone = true;
+            }
+            if (!t->volumeDone) {
+                for (size_t i = 0; i < t->localVolume.size(); ++i) {
+                    t->localVolume[i].alpha /= float(nshot);  // the RUNNING nshot (photonshooter.cpp:333)
+                    volumeOut->push_back(t->localVolume[i]);
+                }
+                t->localVolume.clear();
+                if (volumeOut->size() >= params.n_volume_photons) t->volumeDone = true;
+            }
+            if (t->indirectDone && t->causticDone && t->volumeDone) t->finished = true;
+        }
+    }
+    for (auto *t : tasks) {
+        stats->paths += t->st.paths; stats->follow_calls += t->st.follow_calls; stats->no_hit += t->st.no_hit;
+        stats->march_steps += t->st.march_steps; stats->interactions += t->st.interactions; stats->absorbed += t->st.absorbed;
+        stats->split_children += t->st.split_children;
+        delete t;
+    }
+    stats->stored_volume = volumeOut->size();
+    stats->stored_caustic = nCaustic; stats->stored_direct = nDirect; stats->stored_indirect = nIndirect;
+    stats->nshot = nshot;
+    return rc;
+}
+
+}  // namespace orc
+#endif

@@ -1,0 +1,757 @@
+// oracle/ref_capture.cpp -- TEST INFRASTRUCTURE.  Capture tool linked against the REFERENCE's
+// own objects (oracle/_ref/libpbrtref.a, built by oracle/Makefile from the sources where they
+// lie).  It builds the BASELINE.json scenes through the reference's public Create*() functions
+// exactly as core/api.cpp would from the .pbrt files, flattens them into the pvol_scene layout
+// (the same flattening a drop-in shim performs), and records outputs of the
+// reference's PhotonVolumeIntegrator::Li / Transmittance, lights, shapes, BSDFs, RNG and samplers
+// as golden vectors for tests/golden/.
+//
+// Nothing here restates reference algorithms: every number written comes out of reference code.
+// The only liberty: `private`/`protected` are opened for the reference headers so that object
+// state can be read back (light positions, volume extents, PhotonShooter::volumeMap).  The
+// reference's photon SHOOTER cannot run here: PhotonShootingTask needs core/parallel.cpp, which is
+// unbuildable in this image (see Makefile); photon maps are therefore inputs to this tool.
+#include <algorithm>
+#include <cassert>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <stdint.h>
+#include <pthread.h>
+
+#define private public
+#define protected public
+#include "stdafx.h"
+#include "pbrt.h"
+#include "spectrum.h"
+#include "rng.h"
+#include "montecarlo.h"
+#include "geometry.h"
+#include "transform.h"
+#include "paramset.h"
+#include "scene.h"
+#include "light.h"
+#include "volume.h"
+#include "shape.h"
+#include "primitive.h"
+#include "material.h"
+#include "reflection.h"
+#include "intersection.h"
+#include "renderer.h"
+#include "sampler.h"
+#include "kdtree.h"
+#include "texture.h"
+#include "photonshooter.h"
+#include "integrators/photonvolume.h"
+#include "accelerators/bvh.h"
+#include "lights/distant.h"
+#include "lights/point.h"
+#include "lights/spot.h"
+#include "materials/glass.h"
+#include "materials/matte.h"
+#include "shapes/trianglemesh.h"
+#include "volumes/homogeneous.h"
+#include "volumes/rainbow.h"
+#include "volumes/volumegrid.h"
+#undef private
+#undef protected
+
+#include "pvol.h"
+#include "blob.h"
+
+using blob::Blob;
+
+// ----------------------------------------------------------------------------- scene building
+struct BuiltScene {
+    Scene *scene;
+    VolumeRegion *volume;
+    int volumeKind;
+    std::vector<Light *> lights;
+    std::vector<int> lightKinds;
+    std::vector<TriangleMesh *> meshes;
+    std::vector<int> meshMaterial;
+    struct Mat { int kind; Spectrum kd, kr, kt; float ior, vn; };
+    std::vector<Mat> mats;
+    std::vector<Reference<Material> > matRefs;
+    std::vector<Reference<Primitive> > prims;
+    // integrator parameters from the scene file
+    float stepSize, maxDist, shooterStep;
+    int nUsed, nVolumePhotons, maxPhotonDepth, nCaustic, nIndirect, finalGather;
+    Transform camToWorld;
+    float fov;
+    int xres, yres, spp;
+    std::vector<float> density;
+    int nx, ny, nz;
+};
+
+static Transform *keep(const Transform &t) { return new Transform(t); }
+
+static int addMatte(BuiltScene &B, float r, float g, float b) {
+    ParamSet geom, mat;
+    float rgb[3] = {r, g, b};
+    mat.AddRGBSpectrum("Kd", rgb, 3);
+    map<string, Reference<Texture<float> > > ft;
+    map<string, Reference<Texture<Spectrum> > > st;
+    TextureParams mp(geom, mat, ft, st);
+    Reference<Material> m = CreateMatteMaterial(Transform(), mp);
+    BuiltScene::Mat M;
+    M.kind = PVOL_MATERIAL_MATTE;
+    M.kd = mat.FindOneSpectrum("Kd", Spectrum(0.5f)).Clamp();
+    M.kr = M.kt = Spectrum(0.f);
+    M.ior = 1.f; M.vn = 0.f;
+    B.mats.push_back(M);
+    B.matRefs.push_back(m);
+    return (int)B.mats.size() - 1;
+}
+
+static int addGlass(BuiltScene &B, float ior, float vn, const float kr[3], const float kt[3]) {
+    ParamSet geom, mat;
+    mat.AddFloat("index", &ior, 1);
+    mat.AddFloat("Vn", &vn, 1);
+    mat.AddRGBSpectrum("Kr", kr, 3);
+    mat.AddRGBSpectrum("Kt", kt, 3);
+    map<string, Reference<Texture<float> > > ft;
+    map<string, Reference<Texture<Spectrum> > > st;
+    TextureParams mp(geom, mat, ft, st);
+    Reference<Material> m = CreateGlassMaterial(Transform(), mp);
+    BuiltScene::Mat M;
+    M.kind = PVOL_MATERIAL_GLASS;
+    M.kd = Spectrum(0.f);
+    M.kr = mat.FindOneSpectrum("Kr", Spectrum(1.f)).Clamp();
+    M.kt = mat.FindOneSpectrum("Kt", Spectrum(1.f)).Clamp();
+    M.ior = ior; M.vn = vn;
+    B.mats.push_back(M);
+    B.matRefs.push_back(m);
+    return (int)B.mats.size() - 1;
+}
+
+static void addMesh(BuiltScene &B, const Transform &ctm, const float *P, int nverts, const int *idx, int nidx, int material) {
+    ParamSet ps;
+    std::vector<Point> pts(nverts);
+    for (int i = 0; i < nverts; ++i) pts[i] = Point(P[3 * i], P[3 * i + 1], P[3 * i + 2]);
+    ps.AddPoint("P", &pts[0], nverts);
+    ps.AddInt("indices", idx, nidx);
+    Transform *o2w = keep(ctm), *w2o = keep(Inverse(ctm));
+    TriangleMesh *mesh = CreateTriangleMeshShape(o2w, w2o, false, ps, NULL);
+    B.meshes.push_back(mesh);
+    B.meshMaterial.push_back(material);
+    Reference<Shape> shape(mesh);
+    B.prims.push_back(new GeometricPrimitive(shape, B.matRefs[material], NULL));
+}
+
+static void addQuad(BuiltScene &B, const Transform &ctm, const float P[12], int material) {
+    static const int idx[6] = {0, 1, 2, 2, 3, 0};
+    addMesh(B, ctm, P, 4, idx, 6, material);
+}
+
+static void finish(BuiltScene &B) {
+    ParamSet accelParams;
+    Primitive *accel = CreateBVHAccelerator(B.prims, accelParams);  // core/api.cpp default accelerator "bvh"
+    B.scene = new Scene(accel, B.lights, B.volume);
+}
+
+static VolumeRegion *makeVolume(BuiltScene &B, const Transform &ctm, const char *kind, const float p0[3], const float p1[3],
+                                float sa, float ss, int gridN = 0) {
+    ParamSet ps;
+    float rgbA[3] = {sa, sa, sa}, rgbS[3] = {ss, ss, ss};
+    ps.AddRGBSpectrum("sigma_a", rgbA, 3);
+    ps.AddRGBSpectrum("sigma_s", rgbS, 3);
+    Point a(p0[0], p0[1], p0[2]), b(p1[0], p1[1], p1[2]);
+    ps.AddPoint("p0", &a, 1);
+    ps.AddPoint("p1", &b, 1);
+    if (!strcmp(kind, "homogeneous")) { B.volumeKind = PVOL_VOLUME_HOMOGENEOUS; return CreateHomogeneousVolumeDensityRegion(ctm, ps); }
+    if (!strcmp(kind, "rainbow")) { B.volumeKind = PVOL_VOLUME_RAINBOW; return CreateRainbowVolumeDensityRegion(ctm, ps); }
+    // synthetic heterogeneous grid (BASELINE.json config 4)
+    B.volumeKind = PVOL_VOLUME_GRID;
+    B.nx = B.ny = B.nz = gridN;
+    B.density.resize((size_t)gridN * gridN * gridN);
+    uint32_t h = 348u;
+    for (int z = 0; z < gridN; ++z)
+        for (int y = 0; y < gridN; ++y)
+            for (int x = 0; x < gridN; ++x) {
+                float xh = (x + .5f) / gridN, yh = (y + .5f) / gridN, zh = (z + .5f) / gridN;
+                h = h * 1664525u + 1013904223u;
+                float noise = ((h >> 8) & 0xffff) / 65536.f - .5f;
+                float d = 0.5f + 0.5f * sinf(7.f * xh) * sinf(5.f * yh) * sinf(3.f * zh) + 0.25f * noise;
+                B.density[(size_t)z * gridN * gridN + (size_t)y * gridN + x] = d < 0.f ? 0.f : (d > 1.5f ? 1.5f : d);
+            }
+    ps.AddFloat("density", &B.density[0], (int)B.density.size());
+    ps.AddInt("nx", &gridN, 1);
+    ps.AddInt("ny", &gridN, 1);
+    ps.AddInt("nz", &gridN, 1);
+    return CreateGridVolumeRegion(ctm, ps);
+}
+
+static void addDistant(BuiltScene &B, const Transform &ctm, const float from[3], const float to[3], float L) {
+    ParamSet ps;
+    Point f(from[0], from[1], from[2]), t(to[0], to[1], to[2]);
+    float rgb[3] = {L, L, L};
+    ps.AddPoint("from", &f, 1);
+    ps.AddPoint("to", &t, 1);
+    ps.AddRGBSpectrum("L", rgb, 3);
+    B.lights.push_back(CreateDistantLight(ctm, ps));
+    B.lightKinds.push_back(PVOL_LIGHT_DISTANT);
+}
+static void addSpot(BuiltScene &B, const Transform &ctm, const float from[3], const float to[3], float I, float cone) {
+    ParamSet ps;
+    Point f(from[0], from[1], from[2]), t(to[0], to[1], to[2]);
+    float rgb[3] = {I, I, I};
+    ps.AddPoint("from", &f, 1);
+    ps.AddPoint("to", &t, 1);
+    ps.AddRGBSpectrum("I", rgb, 3);
+    ps.AddFloat("coneangle", &cone, 1);
+    B.lights.push_back(CreateSpotLight(ctm, ps));
+    B.lightKinds.push_back(PVOL_LIGHT_SPOT);
+}
+static void addPoint(BuiltScene &B, const Transform &ctm, const float from[3], float I) {
+    ParamSet ps;
+    Point f(from[0], from[1], from[2]);
+    float rgb[3] = {I, I, I};
+    ps.AddPoint("from", &f, 1);
+    ps.AddRGBSpectrum("I", rgb, 3);
+    B.lights.push_back(CreatePointLight(ctm, ps));
+    B.lightKinds.push_back(PVOL_LIGHT_POINT);
+}
+
+// obj/prism.pbrt (scene input data)
+static const float kPrismP[18] = {1, -1, -1, 1, -1, 1, -1, -1, 1, -1, -1, -1, 1, 1, 9.999999975e-07f, -1, 1, -0.f};
+static const int kPrismIdx[24] = {0, 1, 2, 0, 2, 3, 1, 4, 5, 1, 5, 2, 0, 4, 1, 2, 5, 3, 4, 0, 3, 4, 3, 5};
+
+// projectScene/volumescene_png.pbrt; `volKind` swaps the Volume statement, `gridN` > 0
+// makes the synthetic config-4 variant.
+static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN) {
+    B.stepSize = .15f; B.nUsed = 50; B.maxDist = 0.5f; B.nVolumePhotons = 5000;
+    B.shooterStep = 0.1f; B.maxPhotonDepth = 5; B.nCaustic = 5000; B.nIndirect = 0; B.finalGather = 1;
+    B.xres = B.yres = 300; B.spp = 1; B.fov = 70.f;
+    Transform camCtm = Rotate(0, Vector(0, 1, 0));      // "Rotate 0 1 0 0" before Camera
+    B.camToWorld = Inverse(camCtm);
+    Transform ctm = Transform() * Translate(Vector(0, -0.5f, 3.5f));
+    float p0[3] = {-10, 0, -5}, p1[3] = {5, 5, 5};
+    B.volume = makeVolume(B, ctm, volKind, p0, p1, .05f, .1f, gridN);
+    float from[3] = {0, 3, 0}, to[3] = {0, 2, 5};
+    addDistant(B, ctm, from, to, 150.f);
+    int m = addMatte(B, .01f, .01f, .01f);
+    float q1[12] = {-5, 0, -5, 5, 0, -5, 5, 0, 5, -5, 0, 5};
+    float q2[12] = {-5, 0, 3, 5, 0, 3, 5, 10, 3, -5, 10, 3};
+    float q3[12] = {5, 0, 3, 5, 0, -3, 5, 10, -3, 5, 10, 3};
+    addQuad(B, ctm, q1, m);
+    addQuad(B, ctm, q2, m);
+    addQuad(B, ctm, q3, m);
+    finish(B);
+}
+
+// projectScene/pinkfloyd.pbrt
+static void buildPinkFloyd(BuiltScene &B) {
+    B.stepSize = .05f; B.nUsed = 500; B.maxDist = 0.4f; B.nVolumePhotons = 5000000;
+    B.shooterStep = 0.1f; B.maxPhotonDepth = 5; B.nCaustic = 1; B.nIndirect = 0; B.finalGather = 0;
+    B.xres = B.yres = 512; B.spp = 32; B.fov = 70.f;
+    Transform camCtm = Rotate(5, Vector(1, 0, 0));
+    B.camToWorld = Inverse(camCtm);
+    Transform ctm = Transform() * Translate(Vector(0, -0.5f, 3.5f));
+    float p0[3] = {-10, -10, -10}, p1[3] = {5, 5, 5};
+    B.volume = makeVolume(B, ctm, "homogeneous", p0, p1, .05f, .1f);
+    float sf[3] = {-3, 0.72f, 0}, st[3] = {0, 1.55f, 0};
+    addSpot(B, ctm, sf, st, 15000.f, 0.8f);
+    float pf[3] = {0.1f, 1.35f, -4};
+    addPoint(B, ctm, pf, 4.f);
+    float kr[3] = {0, 0, 0}, kt[3] = {1, 1, 1};
+    int glass = addGlass(B, 1.3f, 2.75f, kr, kt);
+    Transform pctm = ctm * Translate(Vector(0.1f, 1.35f, 0)) * Rotate(90, Vector(0, 1, 0)) * Rotate(0, Vector(1, 0, 0)) *
+                     Scale(0.05f, 0.7f, 0.85f);
+    addMesh(B, pctm, kPrismP, 6, kPrismIdx, 24, glass);
+    int matte = addMatte(B, .001f, .001f, .001f);
+    float q[12] = {5, -20, 3, 5, -20, -3, 5, 20, -3, 5, 20, 3};
+    addQuad(B, ctm, q, matte);
+    finish(B);
+}
+
+// BASELINE.json config 5: homogeneous slab, prism, enclosing matte box, one spot light.
+static void buildShootBench(BuiltScene &B) {
+    B.stepSize = .15f; B.nUsed = 50; B.maxDist = 0.5f; B.nVolumePhotons = 100000000;
+    B.shooterStep = 0.1f; B.maxPhotonDepth = 5; B.nCaustic = 0; B.nIndirect = 0; B.finalGather = 0;
+    B.xres = B.yres = 256; B.spp = 1; B.fov = 70.f;
+    B.camToWorld = Transform();
+    Transform ctm = Transform() * Translate(Vector(0, -0.5f, 3.5f));
+    float p0[3] = {-5, 0, -5}, p1[3] = {5, 5, 5};
+    B.volume = makeVolume(B, ctm, "homogeneous", p0, p1, .05f, .1f);
+    float sf[3] = {-3, 2.5f, 0}, st[3] = {0, 2.5f, 0};
+    addSpot(B, ctm, sf, st, 15000.f, 20.f);
+    float kr[3] = {0, 0, 0}, kt[3] = {1, 1, 1};
+    int glass = addGlass(B, 1.3f, 2.75f, kr, kt);
+    Transform pctm = ctm * Translate(Vector(0.1f, 2.5f, 0)) * Rotate(90, Vector(0, 1, 0)) * Scale(0.3f, 0.7f, 0.85f);
+    addMesh(B, pctm, kPrismP, 6, kPrismIdx, 24, glass);
+    int matte = addMatte(B, .5f, .5f, .5f);
+    // enclosing box (-6,-1,-6)-(6,6,6): photons that never hit a surface are dropped (photonshooter.cpp:54)
+    float bx[24] = {-6, -1, -6, 6, -1, -6, 6, -1, 6, -6, -1, 6, -6, 6, -6, 6, 6, -6, 6, 6, 6, -6, 6, 6};
+    int bi[36] = {0, 1, 2, 2, 3, 0, 4, 6, 5, 6, 4, 7, 0, 4, 5, 5, 1, 0, 1, 5, 6, 6, 2, 1, 2, 6, 7, 7, 3, 2, 3, 7, 4, 4, 0, 3};
+    addMesh(B, ctm, bx, 8, bi, 36, matte);
+    finish(B);
+}
+
+static bool buildByName(BuiltScene &B, const std::string &name) {
+    if (name == "volumescene_h") buildVolumeScene(B, "homogeneous", 0);
+    else if (name == "volumescene_rainbow") buildVolumeScene(B, "rainbow", 0);
+    else if (name == "volumescene_grid16") buildVolumeScene(B, "grid", 16);
+    else if (name == "volumescene_grid128") buildVolumeScene(B, "grid", 128);
+    else if (name == "pinkfloyd") buildPinkFloyd(B);
+    else if (name == "shootbench") buildShootBench(B);
+    else return false;
+    return true;
+}
+
+// ----------------------------------------------------------------------------- flattening
+static void putSpec(std::vector<float> &v, const Spectrum &s) { for (int i = 0; i < nSpectralSamples; ++i) v.push_back(s.c[i]); }
+static void putMat(std::vector<float> &v, const Matrix4x4 &m) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) v.push_back(m.m[r][c]); }
+
+static void flatten(const BuiltScene &B, Blob &out, bool withDensity) {
+    out.puti1("vol.kind", B.volumeKind);
+    std::vector<float> ext, w2v, v2w, sa, ss, le;
+    float g = 0;
+    const BBox *e = 0;
+    const Transform *W2V = 0;
+    if (B.volumeKind == PVOL_VOLUME_GRID) {
+        const VolumeGridDensity *v = (const VolumeGridDensity *)B.volume;
+        e = &v->extent; W2V = &v->WorldToVolume; putSpec(sa, v->sig_a); putSpec(ss, v->sig_s); putSpec(le, v->le); g = v->g;
+    } else {
+        const HomogeneousVolumeDensity *v = (const HomogeneousVolumeDensity *)B.volume;
+        e = &v->extent; W2V = &v->WorldToVolume; putSpec(sa, v->sig_a); putSpec(ss, v->sig_s); putSpec(le, v->le); g = v->g;
+    }
+    float ex[6] = {e->pMin.x, e->pMin.y, e->pMin.z, e->pMax.x, e->pMax.y, e->pMax.z};
+    out.putf("vol.extent", ex, 6);
+    putMat(w2v, W2V->m); putMat(v2w, W2V->mInv);
+    out.putf("vol.w2v", w2v); out.putf("vol.v2w", v2w);
+    out.putf("vol.sigma_a", sa); out.putf("vol.sigma_s", ss); out.putf("vol.le", le);
+    out.putf1("vol.g", g);
+    int32_t dims[3] = {B.nx, B.ny, B.nz};
+    if (B.volumeKind != PVOL_VOLUME_GRID) dims[0] = dims[1] = dims[2] = 0;
+    out.put("vol.dims", blob::I32, dims, 3);
+    if (B.volumeKind == PVOL_VOLUME_GRID && withDensity) out.putf("vol.density", ((const VolumeGridDensity *)B.volume)->density, (size_t)B.nx * B.ny * B.nz);
+
+    std::vector<int32_t> lk;
+    std::vector<float> lpos, ldir, l2w, w2l, lint, lcos;
+    for (size_t i = 0; i < B.lights.size(); ++i) {
+        lk.push_back(B.lightKinds[i]);
+        const Light *L = B.lights[i];
+        putMat(l2w, L->LightToWorld.m); putMat(w2l, L->WorldToLight.m);
+        if (B.lightKinds[i] == PVOL_LIGHT_DISTANT) {
+            const DistantLight *d = (const DistantLight *)L;
+            lpos.insert(lpos.end(), 3, 0.f);
+            ldir.push_back(d->lightDir.x); ldir.push_back(d->lightDir.y); ldir.push_back(d->lightDir.z);
+            putSpec(lint, d->L); lcos.push_back(0.f); lcos.push_back(0.f);
+        } else if (B.lightKinds[i] == PVOL_LIGHT_SPOT) {
+            const SpotLight *s = (const SpotLight *)L;
+            lpos.push_back(s->lightPos.x); lpos.push_back(s->lightPos.y); lpos.push_back(s->lightPos.z);
+            ldir.insert(ldir.end(), 3, 0.f);
+            putSpec(lint, s->Intensity); lcos.push_back(s->cosTotalWidth); lcos.push_back(s->cosFalloffStart);
+        } else {
+            const PointLight *p = (const PointLight *)L;
+            lpos.push_back(p->lightPos.x); lpos.push_back(p->lightPos.y); lpos.push_back(p->lightPos.z);
+            ldir.insert(ldir.end(), 3, 0.f);
+            putSpec(lint, p->Intensity); lcos.push_back(0.f); lcos.push_back(0.f);
+        }
+    }
+    out.put("lights.kind", blob::I32, lk.data(), lk.size());
+    out.putf("lights.pos", lpos); out.putf("lights.dir", ldir); out.putf("lights.l2w", l2w); out.putf("lights.w2l", w2l);
+    out.putf("lights.intensity", lint); out.putf("lights.cos", lcos);
+
+    std::vector<float> tp;
+    std::vector<int32_t> tm, tf;
+    for (size_t k = 0; k < B.meshes.size(); ++k) {
+        const TriangleMesh *mesh = B.meshes[k];
+        for (int t = 0; t < mesh->ntris; ++t) {
+            for (int c = 0; c < 3; ++c) {
+                const Point &p = mesh->p[mesh->vertexIndex[3 * t + c]];
+                tp.push_back(p.x); tp.push_back(p.y); tp.push_back(p.z);
+            }
+            tm.push_back(B.meshMaterial[k]);
+            tf.push_back((mesh->ReverseOrientation ^ mesh->TransformSwapsHandedness) ? 1 : 0);
+        }
+    }
+    out.putf("tris.p", tp);
+    out.put("tris.material", blob::I32, tm.data(), tm.size());
+    out.put("tris.flip", blob::I32, tf.data(), tf.size());
+
+    std::vector<int32_t> mk;
+    std::vector<float> kd, kr, kt, ior, vn;
+    for (size_t i = 0; i < B.mats.size(); ++i) {
+        mk.push_back(B.mats[i].kind);
+        putSpec(kd, B.mats[i].kd); putSpec(kr, B.mats[i].kr); putSpec(kt, B.mats[i].kt);
+        ior.push_back(B.mats[i].ior); vn.push_back(B.mats[i].vn);
+    }
+    out.put("mats.kind", blob::I32, mk.data(), mk.size());
+    out.putf("mats.kd", kd); out.putf("mats.kr", kr); out.putf("mats.kt", kt); out.putf("mats.ior", ior); out.putf("mats.vn", vn);
+
+    const BBox &wb = B.scene->WorldBound();
+    float w[6] = {wb.pMin.x, wb.pMin.y, wb.pMin.z, wb.pMax.x, wb.pMax.y, wb.pMax.z};
+    out.putf("world", w, 6);
+    std::vector<float> cx, cy, cz;
+    putSpec(cx, SampledSpectrum::X); putSpec(cy, SampledSpectrum::Y); putSpec(cz, SampledSpectrum::Z);
+    out.putf("cie.x", cx); out.putf("cie.y", cy); out.putf("cie.z", cz);
+    out.putf1("xyz_scale", float(sampledLambdaEnd - sampledLambdaStart) / float(CIE_Y_integral * nSpectralSamples));
+
+    float pf[3] = {B.stepSize, B.maxDist, B.shooterStep};
+    int32_t pi[6] = {B.nUsed, B.nVolumePhotons, B.maxPhotonDepth, B.nCaustic, B.nIndirect, B.finalGather};
+    out.putf("params.f", pf, 3);
+    out.put("params.i", blob::I32, pi, 6);
+    std::vector<float> c2w;
+    putMat(c2w, B.camToWorld.m);
+    out.putf("camera.c2w", c2w);
+    out.putf1("camera.fov", B.fov);
+    int32_t film[3] = {B.xres, B.yres, B.spp};
+    out.put("film", blob::I32, film, 3);
+}
+
+// ----------------------------------------------------------------------------- capture helpers
+// The caller side of the hot path: SamplerRenderer::Transmittance (renderers/samplerrenderer.cpp:253-258)
+// forwards to the volume integrator.  SamplerRenderer itself cannot be linked (task system).
+class CaptureRenderer : public Renderer {
+public:
+    explicit CaptureRenderer(VolumeIntegrator *v) : vi(v) {}
+    void Render(const Scene *) {}
+    Spectrum Li(const Scene *, const RayDifferential &, const Sample *, RNG &, MemoryArena &, Intersection *, Spectrum *) const { return 0.f; }
+    Spectrum Transmittance(const Scene *scene, const RayDifferential &ray, const Sample *sample, RNG &rng, MemoryArena &arena) const {
+        return vi->Transmittance(scene, this, ray, sample, rng, arena);
+    }
+    VolumeIntegrator *vi;
+};
+
+static uint64_t drawsBetween(RNG &shadow, const RNG &live, uint64_t limit) {
+    // advance `shadow` until it is in the same state as `live`
+    uint64_t k = 0;
+    for (;;) {
+        if (shadow.mti == live.mti && shadow.mt[0] == live.mt[0] && shadow.mt[1] == live.mt[1] && shadow.mt[397] == live.mt[397] &&
+            shadow.mt[623] == live.mt[623])
+            return k;
+        shadow.RandomUInt();
+        if (++k > limit) { fprintf(stderr, "drawsBetween: limit exceeded\n"); exit(2); }
+    }
+}
+
+static Spectrum specFrom(const float *c) { Spectrum s(0.f); for (int i = 0; i < nSpectralSamples; ++i) s.c[i] = c[i]; s.lambda = s.extractLambda(); return s; }
+
+static int cmdScene(const std::string &name, const char *outPath) {
+    BuiltScene B;
+    memset(&B.nx, 0, sizeof(int) * 3);
+    if (!buildByName(B, name)) { fprintf(stderr, "unknown scene %s\n", name.c_str()); return 1; }
+    Blob out;
+    flatten(B, out, name != "volumescene_grid128");  // the 128^3 blob is regenerated by the repo's own generator
+    return out.save(outPath) ? 0 : 1;
+}
+
+static int cmdTables(const char *outPath) {
+    Blob out;
+    std::vector<float> v;
+    putSpec(v, SampledSpectrum::X); out.putf("cie.x", v); v.clear();
+    putSpec(v, SampledSpectrum::Y); out.putf("cie.y", v); v.clear();
+    putSpec(v, SampledSpectrum::Z); out.putf("cie.z", v); v.clear();
+    out.putf1("spectrum1.y", Spectrum(1.f).y());
+    // RNG: first 1300 draws (two table regenerations) for a few seeds
+    const uint32_t seeds[6] = {0u, 1u, 31u, 62u, 4095u, 5489u};
+    out.put("rng.seeds", blob::U32, seeds, 6);
+    std::vector<uint32_t> draws;
+    std::vector<float> fl;
+    for (int s = 0; s < 6; ++s) {
+        RNG r(seeds[s]);
+        for (int i = 0; i < 1300; ++i) draws.push_back(r.RandomUInt());
+        RNG r2(seeds[s]);
+        for (int i = 0; i < 64; ++i) fl.push_back(r2.RandomFloat());
+    }
+    out.putu("rng.draws", draws);
+    out.putf("rng.floats", fl);
+    // PermutedHalton(6, RNG(31*t)) for t = 0,1,2: samples 1..512 plus a few large indices
+    std::vector<float> hal;
+    std::vector<uint32_t> halIdx;
+    for (uint32_t i = 1; i <= 512; ++i) halIdx.push_back(i);
+    const uint32_t big[8] = {4096u, 65535u, 1000003u, 16777216u, 43200000u, 123456789u, 2147483647u, 4294967295u};
+    for (int i = 0; i < 8; ++i) halIdx.push_back(big[i]);
+    for (uint32_t t = 0; t < 3; ++t) {
+        RNG r(31 * t);
+        PermutedHalton h(6, r);
+        for (size_t i = 0; i < halIdx.size(); ++i) { float u[6]; h.Sample(halIdx[i], u); hal.insert(hal.end(), u, u + 6); }
+    }
+    out.putu("halton.index", halIdx);
+    out.putf("halton.samples", hal);
+    // LDShuffleScrambled1D/2D as Li() calls them (nSamples = 1, nPixel = n) and as LDPixelSample does
+    const int ns[5] = {1, 7, 34, 171, 600};
+    std::vector<float> l1, l2;
+    std::vector<uint32_t> lnext;
+    for (int k = 0; k < 5; ++k) {
+        RNG r(1000 + k);
+        std::vector<float> a(ns[k]), b(2 * ns[k]);
+        LDShuffleScrambled1D(1, ns[k], &a[0], r);
+        LDShuffleScrambled2D(1, ns[k], &b[0], r);
+        l1.insert(l1.end(), a.begin(), a.end());
+        l2.insert(l2.end(), b.begin(), b.end());
+        lnext.push_back(r.RandomUInt());
+    }
+    out.put("ld.n", blob::I32, ns, 5);
+    out.putf("ld.1d", l1); out.putf("ld.2d", l2); out.putu("ld.next", lnext);
+    {
+        RNG r(77);
+        std::vector<float> a(4 * 16), b(2 * 4 * 16);
+        LDShuffleScrambled1D(4, 16, &a[0], r);
+        LDShuffleScrambled2D(4, 16, &b[0], r);
+        out.putf("ld.1d_4x16", a); out.putf("ld.2d_4x16", b);
+        out.putu1("ld.next_4x16", r.RandomUInt());
+    }
+    // sampling routines on a lattice
+    std::vector<float> us, sph, cone, disk, cosh;
+    for (int i = 0; i < 17; ++i)
+        for (int j = 0; j < 17; ++j) {
+            float u1 = std::min(i / 16.f, OneMinusEpsilon), u2 = std::min(j / 16.f, OneMinusEpsilon);
+            us.push_back(u1); us.push_back(u2);
+            Vector a = UniformSampleSphere(u1, u2); sph.push_back(a.x); sph.push_back(a.y); sph.push_back(a.z);
+            Vector b = UniformSampleCone(u1, u2, 0.95f); cone.push_back(b.x); cone.push_back(b.y); cone.push_back(b.z);
+            float dx, dy; ConcentricSampleDisk(u1, u2, &dx, &dy); disk.push_back(dx); disk.push_back(dy);
+            Vector c = CosineSampleHemisphere(u1, u2); cosh.push_back(c.x); cosh.push_back(c.y); cosh.push_back(c.z);
+        }
+    out.putf("mc.u", us); out.putf("mc.sphere", sph); out.putf("mc.cone95", cone); out.putf("mc.disk", disk); out.putf("mc.coshemi", cosh);
+    // phase functions
+    std::vector<float> ph;
+    for (int i = 0; i <= 32; ++i) {
+        float c = -1.f + i / 16.f;
+        Vector w(0, 0, 1), wp(sqrtf(std::max(0.f, 1 - c * c)), 0, c);
+        ph.push_back(c);
+        ph.push_back(PhaseHG(w, wp, 0.f)); ph.push_back(PhaseHG(w, wp, 0.6f)); ph.push_back(PhaseHG(w, wp, -0.3f)); ph.push_back(PhaseMieHazy(w, wp));
+    }
+    out.putf("phase", ph);
+    // RGB -> spectrum for the colours the scenes use (core/paramset.cpp:103 path)
+    const float cols[7] = {.05f, .1f, 150.f, .01f, .001f, 15000.f, 4.f};
+    std::vector<float> sp, spy;
+    for (int i = 0; i < 7; ++i) { float rgb[3] = {cols[i], cols[i], cols[i]}; Spectrum s = Spectrum::FromRGB(rgb); putSpec(sp, s); spy.push_back(s.y()); }
+    out.putf("rgb.grey", cols, 7); out.putf("rgb.spectra", sp); out.putf("rgb.y", spy);
+    return out.save(outPath) ? 0 : 1;
+}
+
+// Li()/Transmittance() records.  rays blob: rays.o rays.d [3n], rays.mint rays.maxt rays.time rays.u [n], rays.skip u32[n];
+// streams.seed streams.first streams.n u32[s], streams.start u64[s].  photons blob: p wi [3m], alpha [30m].
+static int cmdLi(const std::string &name, const char *photonPath, const char *rayPath, const char *outPath, int argc, char **argv) {
+    BuiltScene B;
+    memset(&B.nx, 0, sizeof(int) * 3);
+    if (!buildByName(B, name)) return 1;
+    for (int i = 0; i + 1 < argc; i += 2) {  // parameter overrides
+        if (!strcmp(argv[i], "stepsize")) B.stepSize = (float)atof(argv[i + 1]);
+        else if (!strcmp(argv[i], "nused")) B.nUsed = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "maxdist")) B.maxDist = (float)atof(argv[i + 1]);
+    }
+    Blob pb, rb;
+    if (!rb.load(rayPath)) { fprintf(stderr, "cannot read %s\n", rayPath); return 1; }
+    // The shooter object Li() reads volumeMap from (photonvolume.cpp:118), made as core/api.cpp:1225-1230 makes it.
+    ParamSet surfp, volp;
+    PhotonShooter *psh = CreatePhotonShooter(surfp, volp);
+    if (strcmp(photonPath, "-")) {
+        if (!pb.load(photonPath)) { fprintf(stderr, "cannot read %s\n", photonPath); return 1; }
+        size_t m = pb.get("p").count() / 3;
+        const float *pp = pb.get("p").f32(), *pw = pb.get("wi").f32(), *pa = pb.get("alpha").f32();
+        vector<Photon> photons;
+        for (size_t i = 0; i < m; ++i)
+            photons.push_back(Photon(Point(pp[3 * i], pp[3 * i + 1], pp[3 * i + 2]), specFrom(pa + 30 * i), Vector(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2])));
+        if (m) psh->volumeMap = new KdTree<Photon>(photons);  // photonshooter.cpp:502-503
+    }
+    ParamSet vp;
+    vp.AddFloat("stepsize", &B.stepSize, 1);
+    vp.AddInt("nused", &B.nUsed, 1);
+    vp.AddFloat("maxdist", &B.maxDist, 1);
+    PhotonVolumeIntegrator *vi = CreatePhotonVolumeIntegrator(vp, psh);
+    CaptureRenderer renderer(vi);
+    Sample sample(NULL, NULL, vi, B.scene);  // RequestSamples: tauSampleOffset = 0, scatterSampleOffset = 1
+    MemoryArena arena;
+
+    size_t n = rb.get("rays.u").count();
+    const float *ro = rb.get("rays.o").f32(), *rd = rb.get("rays.d").f32(), *rmin = rb.get("rays.mint").f32(), *rmax = rb.get("rays.maxt").f32(),
+                *rt = rb.get("rays.time").f32(), *ru = rb.get("rays.u").f32();
+    const uint32_t *rskip = rb.get("rays.skip").u32();
+    size_t ns = rb.get("streams.seed").count();
+    const uint32_t *sseed = rb.get("streams.seed").u32(), *sfirst = rb.get("streams.first").u32(), *sn = rb.get("streams.n").u32();
+    const uint64_t *sstart = rb.get("streams.start").u64();
+    bool transOnly = rb.has("transmittance_only");
+    std::vector<float> Lv(30 * n, 0.f), T(30 * n, 0.f);
+    std::vector<uint32_t> draws(n, 0), nextRng(ns, 0);
+    std::vector<uint64_t> send(ns, 0);
+    for (size_t s = 0; s < ns; ++s) {
+        RNG rng(sseed[s]), shadow(sseed[s]);
+        uint64_t total = 0;
+        for (uint64_t k = 0; k < sstart[s]; ++k) { rng.RandomUInt(); shadow.RandomUInt(); }
+        total = sstart[s];
+        for (uint32_t k = 0; k < sn[s]; ++k) {
+            size_t i = sfirst[s] + k;
+            for (uint32_t q = 0; q < rskip[i]; ++q) { rng.RandomUInt(); shadow.RandomUInt(); }
+            total += rskip[i];
+            RayDifferential ray(Point(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), Vector(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]), rmin[i], rmax[i], rt[i]);
+            Spectrum Tr(1.f), L(0.f);
+            if (transOnly) {
+                Tr = vi->Transmittance(B.scene, &renderer, ray, NULL, rng, arena);
+            } else {
+                sample.oneD[vi->scatterSampleOffset][0] = ru[i];
+                L = vi->Li(B.scene, &renderer, ray, &sample, rng, &Tr, arena);
+            }
+            arena.FreeAll();
+            uint64_t d = drawsBetween(shadow, rng, 10000000);
+            draws[i] = (uint32_t)d;
+            total += d;
+            for (int b = 0; b < 30; ++b) { Lv[30 * i + b] = L.c[b]; T[30 * i + b] = Tr.c[b]; }
+        }
+        send[s] = total;
+        nextRng[s] = rng.RandomUInt();
+    }
+    Blob out;
+    out.putf("Lv", Lv); out.putf("T", T); out.putu("draws", draws); out.putu("next_rng", nextRng);
+    out.put("streams.end", blob::U64, send.data(), send.size());
+    float pf[3] = {B.stepSize, B.maxDist, B.shooterStep};
+    out.putf("params.f", pf, 3);
+    out.puti1("params.nused", B.nUsed);
+    return out.save(outPath) ? 0 : 1;
+}
+
+// Building blocks of the photon shooter, evaluated by the reference's objects.
+static int cmdUnits(const std::string &name, const char *outPath) {
+    BuiltScene B;
+    memset(&B.nx, 0, sizeof(int) * 3);
+    if (!buildByName(B, name)) return 1;
+    Blob out;
+    const Scene *scene = B.scene;
+    // light power CDF inputs (core/integrator.cpp:261-268)
+    std::vector<float> pw;
+    for (size_t i = 0; i < B.lights.size(); ++i) pw.push_back(B.lights[i]->Power(scene).y());
+    out.putf("light.power_y", pw);
+    // emission: Sample_L(scene, ls, u1, u2, time, &ray, &Ns, &pdf) on a lattice + RNG points
+    RNG rng(2024);
+    std::vector<float> eu, eo;
+    for (size_t li = 0; li < B.lights.size(); ++li)
+        for (int k = 0; k < 64; ++k) {
+            float u0 = rng.RandomFloat(), u1 = rng.RandomFloat();
+            Ray ray; Normal Ns; float pdf;
+            Spectrum Le = B.lights[li]->Sample_L(scene, LightSample(u0, u1, 0.5f), 0.25f, 0.75f, 0.f, &ray, &Ns, &pdf);
+            eu.push_back((float)li); eu.push_back(u0); eu.push_back(u1);
+            float rec[10] = {ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, Ns.x, Ns.y, Ns.z, pdf};
+            eo.insert(eo.end(), rec, rec + 10);
+            putSpec(eo, Le);
+        }
+    out.putf("emit.in", eu); out.putf("emit.out", eo);
+    // Sample_L(p, ...) at random points of the world bound
+    const BBox &wb = scene->WorldBound();
+    std::vector<float> sp, so;
+    for (size_t li = 0; li < B.lights.size(); ++li)
+        for (int k = 0; k < 64; ++k) {
+            Point p = wb.Lerp(rng.RandomFloat(), rng.RandomFloat(), rng.RandomFloat());
+            Vector wi; float pdf; VisibilityTester vis;
+            Spectrum L = B.lights[li]->Sample_L(p, 0.f, LightSample(0.5f, 0.5f, 0.5f), 0.f, &wi, &pdf, &vis);
+            sp.push_back((float)li); sp.push_back(p.x); sp.push_back(p.y); sp.push_back(p.z);
+            float rec[12] = {wi.x, wi.y, wi.z, pdf, vis.r.o.x, vis.r.o.y, vis.r.o.z, vis.r.d.x, vis.r.d.y, vis.r.d.z, vis.r.mint, vis.r.maxt};
+            so.insert(so.end(), rec, rec + 12);
+            putSpec(so, L);
+        }
+    out.putf("sample.in", sp); out.putf("sample.out", so);
+    // closest hit / any hit / BSDF sampling along random rays
+    std::vector<float> ri, ro_, bs;
+    MemoryArena arena;
+    int nr = 0;
+    for (int k = 0; k < 4000 && nr < 600; ++k) {
+        Point o = wb.Lerp(rng.RandomFloat(), rng.RandomFloat(), rng.RandomFloat());
+        Vector d = UniformSampleSphere(rng.RandomFloat(), rng.RandomFloat());
+        float maxt = (k % 3 == 0) ? 4.f * rng.RandomFloat() : INFINITY;
+        RayDifferential ray(o, d, 0.f, maxt, 0.f);
+        Intersection isect;
+        bool hitP = scene->IntersectP(ray);
+        bool hit = scene->Intersect(ray, &isect);
+        if (!hit && (k % 4)) continue;  // keep some misses
+        ++nr;
+        float in[7] = {o.x, o.y, o.z, d.x, d.y, d.z, maxt};
+        ri.insert(ri.end(), in, in + 7);
+        float rec[12] = {hit ? 1.f : 0.f, hitP ? 1.f : 0.f, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (hit) {
+            rec[2] = ray.maxt; rec[3] = isect.dg.p.x; rec[4] = isect.dg.p.y; rec[5] = isect.dg.p.z;
+            rec[6] = isect.dg.nn.x; rec[7] = isect.dg.nn.y; rec[8] = isect.dg.nn.z;
+            rec[9] = isect.dg.dpdu.x; rec[10] = isect.dg.dpdu.y; rec[11] = isect.dg.dpdu.z;
+        }
+        ro_.insert(ro_.end(), rec, rec + 12);
+        // BSDF::Sample_f exactly as followPhoton calls it (photonshooter.cpp:202-203), once with a
+        // polychromatic alpha and once with a monochromatic one (dispersion path)
+        for (int variant = 0; variant < 2; ++variant) {
+            float u0 = rng.RandomFloat(), u1 = rng.RandomFloat(), uc = rng.RandomFloat();
+            int bin = (int)(rng.RandomFloat() * 30);
+            float rec2[41];
+            memset(rec2, 0, sizeof(rec2));
+            rec2[0] = u0; rec2[1] = u1; rec2[2] = uc; rec2[3] = (float)bin;
+            if (hit) {
+                Spectrum alpha(1.f);
+                alpha.lambda = -1;
+                if (variant == 1) { alpha = Spectrum(0.f); alpha.c[bin] = 0.7f; alpha.lambda = alpha.extractLambda(); }
+                BSDF *bsdf = isect.GetBSDF(ray, arena);
+                Vector wo = -ray.d, wi(0, 0, 0);
+                float pdf = 0; BxDFType flags = BxDFType(0);
+                Spectrum f = bsdf->Sample_f(wo, &wi, BSDFSample(u0, u1, uc), &pdf, BSDF_ALL, &flags, &alpha);
+                rec2[4] = wi.x; rec2[5] = wi.y; rec2[6] = wi.z; rec2[7] = pdf; rec2[8] = (float)(int)flags;
+                rec2[9] = (float)bsdf->NumComponents();
+                rec2[10] = isect.primitive->dispersive() ? 1.f : 0.f;
+                for (int b = 0; b < 30; ++b) rec2[11 + b] = f.c[b];
+                arena.FreeAll();
+            }
+            bs.insert(bs.end(), rec2, rec2 + 41);
+        }
+    }
+    out.putf("hit.in", ri); out.putf("hit.out", ro_); out.putf("bsdf.out", bs);
+    // volume queries
+    std::vector<float> vq, vo;
+    const VolumeRegion *vr = scene->volumeRegion;
+    BBox vb = vr->WorldBound();
+    vb.Expand(0.5f);
+    for (int k = 0; k < 256; ++k) {
+        Point p = vb.Lerp(rng.RandomFloat(), rng.RandomFloat(), rng.RandomFloat());
+        Vector d = UniformSampleSphere(rng.RandomFloat(), rng.RandomFloat());
+        float len = 0.2f + 6.f * rng.RandomFloat();
+        Ray r(p, d, 0.f, len, 0.f);
+        float t0 = -1, t1 = -1;
+        bool hit = vr->IntersectP(r, &t0, &t1);
+        float step = 0.3f, offs = rng.RandomFloat();
+        Spectrum tau = vr->tau(r, step, offs);
+        float in[9] = {p.x, p.y, p.z, d.x, d.y, d.z, len, step, offs};
+        vq.insert(vq.end(), in, in + 9);
+        vo.push_back(hit ? 1.f : 0.f); vo.push_back(t0); vo.push_back(t1);
+        putSpec(vo, tau);
+        putSpec(vo, vr->sigma_a(p, d, 0.f));
+        putSpec(vo, vr->sigma_s(p, d, 0.f));
+        vo.push_back(vr->p(p, d, -d, 0.f));
+    }
+    out.putf("vol.in", vq); out.putf("vol.out", vo);
+    if (B.volumeKind == PVOL_VOLUME_RAINBOW) {
+        std::vector<float> rbw;
+        RainbowVolume *rv = (RainbowVolume *)vr;
+        float rgb[3] = {3, 3, 3};
+        Spectrum Ld = Spectrum::FromRGB(rgb);
+        for (int k = 0; k < 512; ++k) {
+            // sweep the scattering angle through both bows plus random directions
+            float th = (k < 400) ? Radians(38.f + 18.f * k / 400.f) : acosf(1 - 2 * rng.RandomFloat());
+            Vector w(0, 0, 1), wi(sinf(th), 0, -cosf(th));
+            Spectrum r = rv->rainbowReflection(Ld, w, wi);
+            rbw.push_back(w.x); rbw.push_back(w.y); rbw.push_back(w.z); rbw.push_back(wi.x); rbw.push_back(wi.y); rbw.push_back(wi.z);
+            putSpec(rbw, r);
+        }
+        std::vector<float> ldv; putSpec(ldv, Ld);
+        out.putf("rainbow.Ld", ldv);
+        out.putf("rainbow", rbw);
+    }
+    return out.save(outPath) ? 0 : 1;
+}
+
+int main(int argc, char **argv) {
+    SampledSpectrum::Init();  // pbrtInit (core/api.cpp) does this
+    if (argc >= 3 && !strcmp(argv[1], "tables")) return cmdTables(argv[2]);
+    if (argc >= 4 && !strcmp(argv[1], "scene")) return cmdScene(argv[2], argv[3]);
+    if (argc >= 4 && !strcmp(argv[1], "units")) return cmdUnits(argv[2], argv[3]);
+    if (argc >= 6 && !strcmp(argv[1], "li")) return cmdLi(argv[2], argv[3], argv[4], argv[5], argc - 6, argv + 6);
+    fprintf(stderr,
+            "usage: ref_capture tables OUT | scene NAME OUT | units NAME OUT | li NAME PHOTONS|- RAYS OUT [stepsize v] [nused v] [maxdist v]\n");
+    return 64;
+}

@@ -1,0 +1,70 @@
+"""Shared test plumbing.  `-m "not gpu"` covers the oracle against the golden vectors, host
+logic and the C-ABI surface; `-m gpu` holds the HIP-vs-oracle parity tests proper."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pkg = importlib.import_module("cs348b-pbrt_amd")
+abi, blob = pkg.abi, pkg.blob
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import orc as _orc
+    _orc.build()
+    return _orc
+
+
+def load_scene(name):
+    return blob.load(os.path.join(GOLD, "scene_%s.bin" % name))
+
+
+def load_photons(tag):
+    b = blob.load(os.path.join(GOLD, "photons_%s.bin" % tag))
+    return b["p"].reshape(-1, 3), b["wi"].reshape(-1, 3), b["alpha"].reshape(-1, 30)
+
+
+# golden Li() cases: name -> (scene, photon map tag)
+LI_CASES = {
+    "vh": ("volumescene_h", "vh"),
+    "vh_sparse": ("volumescene_h", "vh"),
+    "vh_k500": ("volumescene_h", "vh"),
+    "vh_nomap": ("volumescene_h", None),
+    "rainbow": ("volumescene_rainbow", None),
+    "grid16": ("volumescene_grid16", "grid16"),
+    "pf": ("pinkfloyd", "pf"),
+    "pf_k50": ("pinkfloyd", "pf"),
+}
+TRANS_CASES = {"trans_vh": "volumescene_h", "trans_grid16": "volumescene_grid16"}
+
+
+def load_li_case(name):
+    """Returns (scene blob, params, rays, streams, case blob) for a golden Li()/Transmittance() case."""
+    c = blob.load(os.path.join(GOLD, "li_%s.bin" % name))
+    scene_name = LI_CASES[name][0] if name in LI_CASES else TRANS_CASES[name]
+    s = load_scene(scene_name)
+    p = abi.params_from_blob(s, step_size=float(c["params.f"][0]), max_dist=float(c["params.f"][1]),
+                             n_used=int(c["params.nused"][0]))
+    rays = abi.make_rays(c["rays.o"].reshape(-1, 3), c["rays.d"].reshape(-1, 3), c["rays.mint"], c["rays.maxt"],
+                         c["rays.u"], c["rays.time"], c["rays.skip"])
+    streams = abi.make_streams(c["streams.seed"], c["streams.n"], c["streams.start"])
+    return s, p, rays, streams, c
+
+
+def rel_l2(a, b, axis=-1, floor=1e-30):
+    """Per-row relative L2 error ||a-b|| / max(||b||, floor)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return np.linalg.norm(a - b, axis=axis) / np.maximum(np.linalg.norm(b, axis=axis), floor)

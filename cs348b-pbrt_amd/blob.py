@@ -2,7 +2,7 @@
 
 Layout (little endian): b"PVB1", u32 n_entries, then per entry
   char name[48] (NUL padded), u32 dtype (0=f32 1=u32 2=i32 3=u64), u64 count, payload.
-The C++ side is oracle/blob.h.
+A C++ reader/writer of the same layout lives with the test tooling.
 """
 import struct
 

@@ -1,0 +1,480 @@
+// pvol_api.hip -- the C ABI of include/pvol.h: context, scene flattening to the device layout,
+// photon-map upload + grid build, kernel launches.  There is NO CPU fallback: every entry point
+// that needs the GPU returns PVOL_E_NO_DEVICE when HIP is unusable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "pvol_dev.h"
+
+// ---- kernels' host entry points (pvol_march.hip, pvol_grid.hip)
+struct LiArgs {
+    const DevScene *scene;
+    const pvol_ray *rays;
+    pvol_stream *streams;
+    uint32_t nStreams;
+    int outputKind;
+    float *out;
+    uint32_t *draws;
+    const uint32_t *initState;
+    uint32_t *finalState;
+    DevCounters *counters;
+    int transmittanceOnly;
+};
+struct GridBuildArgs {
+    const float *p, *wi, *alpha;
+    uint32_t n;
+    float lo[3];
+    float inv;
+    int32_t gdim[3];
+    int32_t volKind;
+    float extLo[3], extHi[3];
+    float w2v[16];
+};
+extern "C" hipError_t pvol_launch_li(const LiArgs *args, size_t ldsBytes, bool stats, hipStream_t stream);
+extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
+                                      uint32_t *cellStart, hipStream_t stream);
+
+struct pvol_ctx {
+    pvol_params params;
+    bool haveScene;
+    DevScene hs;         // host copy
+    DevScene *ds;        // device copy
+    float *dDensity;
+    // photon map
+    uint32_t nPhotons;
+    float *dRawP, *dRawWi, *dRawAlpha;  // upload order (kept for pvol_download_photons)
+    float4 *dPos4, *dAlpha4, *dWi4;
+    uint32_t *dCellStart;
+    DevCounters *dCounters;
+    bool statsOn;
+    // kernel timing (HIP events on the launch stream)
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > pool;
+    double timeMs;
+    uint64_t launches;
+    std::mutex mu;
+};
+
+static bool ok(hipError_t e) { return e == hipSuccess; }
+
+extern "C" {
+
+int pvol_abi_version(void) { return PVOL_ABI_VERSION; }
+
+const char *pvol_strerror(int s) {
+    switch (s) {
+    case PVOL_OK: return "ok";
+    case PVOL_E_INVALID: return "invalid argument";
+    case PVOL_E_NO_DEVICE: return "no usable HIP device (this library has no CPU path)";
+    case PVOL_E_NO_SCENE: return "no scene set";
+    case PVOL_E_NO_MEMORY: return "out of memory";
+    case PVOL_E_UNSUPPORTED: return "unsupported volume/light/material kind or size";
+    case PVOL_E_LIMIT: return "a ray needs more march steps than the kernel's LDS plan";
+    case PVOL_E_SHOOT_FAILED: return "unable to store enough photons";
+    default: return "unknown status";
+    }
+}
+
+int pvol_device_count(void) {
+    int n = 0;
+    if (!ok(hipGetDeviceCount(&n))) return 0;
+    return n;
+}
+
+void pvol_default_params(pvol_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->step_size = 1.f;          // photonvolume.cpp:225
+    p->n_used = 250;             // photonvolume.cpp:226
+    p->max_dist = 0.1f;          // photonvolume.cpp:227
+    p->n_volume_photons = 0;     // photonshooter.cpp:532
+    p->shooter_step_size = 0.1f; // photonshooter.cpp:533
+    p->max_photon_depth = 5;     // photonshooter.cpp:539
+    p->n_caustic_photons = 20000;
+    p->n_indirect_photons = 10000;
+    p->final_gather = 1;
+    p->device = 0;
+    p->grid_cell_scale = 0.f;
+}
+
+int pvol_create(const pvol_params *params, pvol_ctx **out) {
+    if (!params || !out) return PVOL_E_INVALID;
+    *out = 0;
+    if (params->n_used < 1 || !(params->step_size > 0.f) || !(params->max_dist > 0.f)) return PVOL_E_INVALID;
+    int n = 0;
+    if (!ok(hipGetDeviceCount(&n)) || n <= 0 || params->device < 0 || params->device >= n) return PVOL_E_NO_DEVICE;
+    if (!ok(hipSetDevice(params->device))) return PVOL_E_NO_DEVICE;
+    pvol_ctx *c = new (std::nothrow) pvol_ctx();
+    if (!c) return PVOL_E_NO_MEMORY;
+    c->params = *params;
+    c->haveScene = false;
+    memset(&c->hs, 0, sizeof(c->hs));
+    c->ds = 0; c->dDensity = 0;
+    c->nPhotons = 0;
+    c->dRawP = c->dRawWi = c->dRawAlpha = 0;
+    c->dPos4 = c->dAlpha4 = c->dWi4 = 0;
+    c->dCellStart = 0;
+    c->dCounters = 0;
+    c->statsOn = false;
+    c->timeMs = 0; c->launches = 0;
+    if (!ok(hipMalloc(&c->ds, sizeof(DevScene))) || !ok(hipMalloc(&c->dCounters, sizeof(DevCounters))) ||
+        !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) {
+        if (c->ds) hipFree(c->ds);
+        if (c->dCounters) hipFree(c->dCounters);
+        delete c;
+        return PVOL_E_NO_DEVICE;
+    }
+    *out = c;
+    return PVOL_OK;
+}
+
+static void free_photons(pvol_ctx *c) {
+    if (c->dRawP) hipFree(c->dRawP);
+    if (c->dRawWi) hipFree(c->dRawWi);
+    if (c->dRawAlpha) hipFree(c->dRawAlpha);
+    if (c->dPos4) hipFree(c->dPos4);
+    if (c->dAlpha4) hipFree(c->dAlpha4);
+    if (c->dWi4) hipFree(c->dWi4);
+    if (c->dCellStart) hipFree(c->dCellStart);
+    c->dRawP = c->dRawWi = c->dRawAlpha = 0;
+    c->dPos4 = c->dAlpha4 = c->dWi4 = 0;
+    c->dCellStart = 0;
+    c->nPhotons = 0;
+}
+
+void pvol_destroy(pvol_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->params.device);
+    hipDeviceSynchronize();
+    free_photons(c);
+    for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (c->dDensity) hipFree(c->dDensity);
+    if (c->ds) hipFree(c->ds);
+    if (c->dCounters) hipFree(c->dCounters);
+    delete c;
+}
+
+static void pad32(float *dst, const pvol_spectrum &s) {
+    for (int i = 0; i < 30; ++i) dst[i] = s.c[i];
+    dst[30] = dst[31] = 0.f;
+}
+
+static int push_scene(pvol_ctx *c) {
+    return ok(hipMemcpy(c->ds, &c->hs, sizeof(DevScene), hipMemcpyHostToDevice)) ? PVOL_OK : PVOL_E_NO_DEVICE;
+}
+
+int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
+    if (!c || !s) return PVOL_E_INVALID;
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    const pvol_volume &v = s->volume;
+    if (v.kind != PVOL_VOLUME_NONE && v.kind != PVOL_VOLUME_HOMOGENEOUS && v.kind != PVOL_VOLUME_GRID && v.kind != PVOL_VOLUME_RAINBOW)
+        return PVOL_E_UNSUPPORTED;
+    if (s->n_lights > PVOL_MAX_LIGHTS || s->n_triangles > PVOL_MAX_TRIS) return PVOL_E_UNSUPPORTED;
+    if ((s->n_lights && !s->lights) || (s->n_triangles && !s->triangles)) return PVOL_E_INVALID;
+    DevScene &h = c->hs;
+    // keep the photon-map fields, replace everything else
+    h.volKind = v.kind;
+    for (int i = 0; i < 3; ++i) { h.extLo[i] = v.extent_min[i]; h.extHi[i] = v.extent_max[i]; }
+    memcpy(h.w2v, v.world_to_volume, sizeof(h.w2v));
+    pad32(h.sigA, v.sigma_a); pad32(h.sigS, v.sigma_s); pad32(h.le, v.le);
+    h.g = v.g;
+    h.nx = v.nx; h.ny = v.ny; h.nz = v.nz;
+    if (c->dDensity) { hipFree(c->dDensity); c->dDensity = 0; }
+    h.density = 0;
+    if (v.kind == PVOL_VOLUME_GRID) {
+        if (!v.density || v.nx < 1 || v.ny < 1 || v.nz < 1) return PVOL_E_INVALID;
+        size_t nb = sizeof(float) * (size_t)v.nx * v.ny * v.nz;
+        if (!ok(hipMalloc(&c->dDensity, nb))) return PVOL_E_NO_MEMORY;
+        if (!ok(hipMemcpy(c->dDensity, v.density, nb, hipMemcpyHostToDevice))) return PVOL_E_NO_DEVICE;
+        h.density = c->dDensity;
+    }
+    h.nLights = (int)s->n_lights;
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const pvol_light &l = s->lights[i];
+        if (l.kind != PVOL_LIGHT_POINT && l.kind != PVOL_LIGHT_SPOT && l.kind != PVOL_LIGHT_DISTANT) return PVOL_E_UNSUPPORTED;
+        DevLight &d = h.lights[i];
+        d.kind = l.kind;
+        for (int k = 0; k < 3; ++k) { d.pos[k] = l.pos[k]; d.dir[k] = l.dir[k]; }
+        memcpy(d.w2l, l.world_to_light, sizeof(float) * 12);
+        d.cosTotalWidth = l.cos_total_width;
+        d.cosFalloffStart = l.cos_falloff_start;
+        pad32(d.intensity, l.intensity);
+    }
+    h.nTris = (int)s->n_triangles;
+    for (uint32_t i = 0; i < s->n_triangles; ++i) {
+        const pvol_triangle &t = s->triangles[i];
+        for (int k = 0; k < 3; ++k) { h.tris[i].p1[k] = t.p[0][k]; h.tris[i].p2[k] = t.p[1][k]; h.tris[i].p3[k] = t.p[2][k]; }
+    }
+    pad32(h.cieX, s->cie_x); pad32(h.cieY, s->cie_y); pad32(h.cieZ, s->cie_z);
+    h.stepSize = c->params.step_size;
+    h.maxDist = c->params.max_dist;
+    h.maxDistSq = c->params.max_dist * c->params.max_dist;  // photonvolume.h:18
+    h.nUsed = c->params.n_used;
+    h.candCap = ((c->params.n_used + 63) / 64) * 64 + 192;
+    // march-step bound: diagonal of the volume's world bound / stepSize (rays are clipped to the extent)
+    h.maxSteps = 0;
+    if (s->n_lights > 1 && v.kind != PVOL_VOLUME_NONE) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = 0; k < 8; ++k) {
+            float x = (k & 1) ? v.extent_max[0] : v.extent_min[0], y = (k & 2) ? v.extent_max[1] : v.extent_min[1],
+                  z = (k & 4) ? v.extent_max[2] : v.extent_min[2];
+            const float *m = v.volume_to_world;
+            float w[3] = {m[0] * x + m[1] * y + m[2] * z + m[3], m[4] * x + m[5] * y + m[6] * z + m[7], m[8] * x + m[9] * y + m[10] * z + m[11]};
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], w[a]); hi[a] = std::max(hi[a], w[a]); }
+        }
+        double diag = sqrt((double)(hi[0] - lo[0]) * (hi[0] - lo[0]) + (double)(hi[1] - lo[1]) * (hi[1] - lo[1]) + (double)(hi[2] - lo[2]) * (hi[2] - lo[2]));
+        double steps = diag / c->params.step_size * 1.05 + 4;
+        if (steps > 12000) return PVOL_E_LIMIT;
+        h.maxSteps = ((int)steps + 63) & ~63;
+    }
+    c->haveScene = true;
+    return push_scene(c);
+}
+
+static void choose_grid(pvol_ctx *c, const float *p, uint32_t n) {
+    DevScene &h = c->hs;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[3 * i + a]); hi[a] = std::max(hi[a], p[3 * i + a]); }
+    double ext[3], vol = 1;
+    const float maxDist = c->params.max_dist;
+    for (int a = 0; a < 3; ++a) { ext[a] = std::max((double)hi[a] - lo[a], 1e-3 * maxDist); vol *= ext[a]; }
+    // aim at ~4 photons per cell, never more than PVOL_MAX_RING rings per lookup, at most 2^24 cells
+    double cell = cbrt(vol * 4.0 / std::max(1u, n));
+    if (c->params.grid_cell_scale > 0.f) cell *= c->params.grid_cell_scale;
+    cell = std::max(cell, (double)maxDist / PVOL_MAX_RING * 1.0001);
+    for (;;) {
+        double cells = 1;
+        for (int a = 0; a < 3; ++a) cells *= floor(ext[a] / cell) + 1;
+        if (cells <= 16777216.0) break;
+        cell *= 1.26;
+    }
+    h.cellSize = (float)cell;
+    h.invCell = 1.f / h.cellSize;
+    for (int a = 0; a < 3; ++a) {
+        h.gridLo[a] = lo[a];
+        h.gdim[a] = (int)floor(ext[a] / cell) + 1;
+    }
+    h.ringMax = (int)ceil(maxDist / h.cellSize);
+    if (h.ringMax > PVOL_MAX_RING) h.ringMax = PVOL_MAX_RING;
+    if (h.ringMax < 1) h.ringMax = 1;
+}
+
+int pvol_upload_photons(pvol_ctx *c, const float *p, const float *wi, const float *alpha, uint32_t n) {
+    if (!c) return PVOL_E_INVALID;
+    if (!c->haveScene) return PVOL_E_NO_SCENE;
+    if (n && (!p || !wi || !alpha)) return PVOL_E_INVALID;
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    hipDeviceSynchronize();
+    free_photons(c);
+    DevScene &h = c->hs;
+    h.nPhotons = 0; h.cellStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
+    if (n == 0) return push_scene(c);
+    choose_grid(c, p, n);
+    size_t ncells = (size_t)h.gdim[0] * h.gdim[1] * h.gdim[2];
+    bool good = ok(hipMalloc(&c->dRawP, sizeof(float) * 3 * (size_t)n)) && ok(hipMalloc(&c->dRawWi, sizeof(float) * 3 * (size_t)n)) &&
+                ok(hipMalloc(&c->dRawAlpha, sizeof(float) * 30 * (size_t)n)) && ok(hipMalloc(&c->dPos4, sizeof(float4) * (size_t)n)) &&
+                ok(hipMalloc(&c->dAlpha4, sizeof(float4) * 8 * (size_t)n)) && ok(hipMalloc(&c->dWi4, sizeof(float4) * (size_t)n)) &&
+                ok(hipMalloc(&c->dCellStart, sizeof(uint32_t) * (ncells + 1)));
+    if (!good) { free_photons(c); push_scene(c); return PVOL_E_NO_MEMORY; }
+    good = ok(hipMemcpy(c->dRawP, p, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice)) &&
+           ok(hipMemcpy(c->dRawWi, wi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice)) &&
+           ok(hipMemcpy(c->dRawAlpha, alpha, sizeof(float) * 30 * (size_t)n, hipMemcpyHostToDevice));
+    GridBuildArgs g;
+    g.p = c->dRawP; g.wi = c->dRawWi; g.alpha = c->dRawAlpha; g.n = n;
+    for (int a = 0; a < 3; ++a) { g.lo[a] = h.gridLo[a]; g.gdim[a] = h.gdim[a]; g.extLo[a] = h.extLo[a]; g.extHi[a] = h.extHi[a]; }
+    g.inv = h.invCell;
+    g.volKind = h.volKind;
+    memcpy(g.w2v, h.w2v, sizeof(g.w2v));
+    good = good && ok(pvol_build_grid(&g, c->dPos4, c->dAlpha4, c->dWi4, c->dCellStart, 0));
+    if (!good) { free_photons(c); push_scene(c); return PVOL_E_NO_DEVICE; }
+    c->nPhotons = n;
+    h.nPhotons = n; h.cellStart = c->dCellStart; h.pos4 = c->dPos4; h.alpha4 = c->dAlpha4; h.wi4 = c->dWi4;
+    return push_scene(c);
+}
+
+int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
+    (void)n_tasks;
+    if (!c) return PVOL_E_INVALID;
+    if (!c->haveScene) return PVOL_E_NO_SCENE;
+    return PVOL_E_UNSUPPORTED;  // device photon shooter: see pvol_shoot.hip (not built yet)
+}
+
+int pvol_photon_count(pvol_ctx *c, uint32_t *n) {
+    if (!c || !n) return PVOL_E_INVALID;
+    *n = c->nPhotons;
+    return PVOL_OK;
+}
+
+int pvol_download_photons(pvol_ctx *c, float *p, float *wi, float *alpha, uint32_t capacity) {
+    if (!c || !p || !wi || !alpha) return PVOL_E_INVALID;
+    uint32_t n = std::min(capacity, c->nPhotons);
+    if (!n) return PVOL_OK;
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    bool good = ok(hipMemcpy(p, c->dRawP, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost)) &&
+                ok(hipMemcpy(wi, c->dRawWi, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost)) &&
+                ok(hipMemcpy(alpha, c->dRawAlpha, sizeof(float) * 30 * (size_t)n, hipMemcpyDeviceToHost));
+    return good ? PVOL_OK : PVOL_E_NO_DEVICE;
+}
+
+static size_t lds_bytes(const pvol_ctx *c) { return 624 * 4 + (size_t)c->hs.candCap * 8 + (size_t)c->hs.maxSteps * 4; }
+
+static int launch(pvol_ctx *c, const pvol_ray *dRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind, float *dOut,
+                  uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, hipStream_t stream) {
+    LiArgs a;
+    a.scene = c->ds; a.rays = dRays; a.streams = dStreams; a.nStreams = nStreams; a.outputKind = outputKind;
+    a.out = dOut; a.draws = dDraws; a.initState = dInit; a.finalState = dFinal; a.counters = c->dCounters;
+    a.transmittanceOnly = transOnly;
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        if (!c->pool.empty()) { ev = c->pool.back(); c->pool.pop_back(); }
+        else if (!ok(hipEventCreate(&ev.first)) || !ok(hipEventCreate(&ev.second))) return PVOL_E_NO_DEVICE;
+    }
+    hipEventRecord(ev.first, stream);
+    hipError_t e = pvol_launch_li(&a, lds_bytes(c), c->statsOn, stream);
+    hipEventRecord(ev.second, stream);
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        c->pending.push_back(ev);
+    }
+    return ok(e) ? PVOL_OK : PVOL_E_NO_DEVICE;
+}
+
+int pvol_li_batch_device(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams,
+                         int outputKind, float *dOut, uint32_t *dDraws, void *hipStream) {
+    if (!c || (nRays && !dRays) || (nStreams && !dStreams) || (nRays && !dOut)) return PVOL_E_INVALID;
+    if (outputKind != PVOL_OUT_SPECTRAL && outputKind != PVOL_OUT_XYZ) return PVOL_E_INVALID;
+    if (!c->haveScene) return PVOL_E_NO_SCENE;
+    if (!nStreams) return PVOL_OK;
+    return launch(c, dRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, (hipStream_t)hipStream);
+}
+
+static int check_errors(pvol_ctx *c) {
+    DevCounters h;
+    if (!ok(hipMemcpy(&h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost))) return PVOL_E_NO_DEVICE;
+    if (h.nErrors) {
+        unsigned long long zero = 0;
+        hipMemcpy(&c->dCounters->nErrors, &zero, sizeof(zero), hipMemcpyHostToDevice);
+        return PVOL_E_LIMIT;
+    }
+    return PVOL_OK;
+}
+
+static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_stream *streams, uint32_t nStreams, int outputKind,
+                      float *out, uint32_t *draws, uint32_t *mtState, int transOnly) {
+    if (!c || (nRays && (!rays || !out)) || (nStreams && !streams)) return PVOL_E_INVALID;
+    if (!c->haveScene) return PVOL_E_NO_SCENE;
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    for (uint32_t s = 0; s < nStreams; ++s)
+        if ((uint64_t)streams[s].first_ray + streams[s].n_rays > nRays) return PVOL_E_INVALID;
+    if (!nStreams || !nRays) return PVOL_OK;
+    const size_t width = transOnly ? 60 : (outputKind == PVOL_OUT_SPECTRAL ? 60 : 4);
+    pvol_ray *dRays = 0; pvol_stream *dStreams = 0; float *dOut = 0; uint32_t *dDraws = 0, *dState = 0;
+    int rc = PVOL_OK;
+    bool good = ok(hipMalloc(&dRays, sizeof(pvol_ray) * (size_t)nRays)) && ok(hipMalloc(&dStreams, sizeof(pvol_stream) * (size_t)nStreams)) &&
+                ok(hipMalloc(&dOut, sizeof(float) * width * nRays)) && ok(hipMalloc(&dDraws, sizeof(uint32_t) * (size_t)nRays));
+    if (good && mtState) good = ok(hipMalloc(&dState, sizeof(uint32_t) * 625 * (size_t)nStreams));
+    if (!good) rc = PVOL_E_NO_MEMORY;
+    if (rc == PVOL_OK) {
+        good = ok(hipMemcpy(dRays, rays, sizeof(pvol_ray) * (size_t)nRays, hipMemcpyHostToDevice)) &&
+               ok(hipMemcpy(dStreams, streams, sizeof(pvol_stream) * (size_t)nStreams, hipMemcpyHostToDevice)) &&
+               ok(hipMemset(dOut, 0, sizeof(float) * width * nRays));
+        if (good && mtState) good = ok(hipMemcpy(dState, mtState, sizeof(uint32_t) * 625 * (size_t)nStreams, hipMemcpyHostToDevice));
+        if (!good) rc = PVOL_E_NO_DEVICE;
+    }
+    if (rc == PVOL_OK) rc = launch(c, dRays, dStreams, nStreams, transOnly ? PVOL_OUT_SPECTRAL : outputKind, dOut, dDraws, dState, dState, transOnly, 0);
+    if (rc == PVOL_OK && !ok(hipDeviceSynchronize())) rc = PVOL_E_NO_DEVICE;
+    if (rc == PVOL_OK) rc = check_errors(c);
+    if (rc == PVOL_OK) {
+        if (transOnly) {
+            // kernel wrote [Lv(30) | T(30)] rows; the ABI returns T only
+            std::vector<float> tmp(width * nRays);
+            good = ok(hipMemcpy(tmp.data(), dOut, sizeof(float) * width * nRays, hipMemcpyDeviceToHost));
+            if (good) for (uint32_t i = 0; i < nRays; ++i) memcpy(out + (size_t)i * 30, tmp.data() + (size_t)i * 60 + 30, sizeof(float) * 30);
+        } else {
+            good = ok(hipMemcpy(out, dOut, sizeof(float) * width * nRays, hipMemcpyDeviceToHost));
+        }
+        good = good && ok(hipMemcpy(streams, dStreams, sizeof(pvol_stream) * (size_t)nStreams, hipMemcpyDeviceToHost));
+        if (good && draws) good = ok(hipMemcpy(draws, dDraws, sizeof(uint32_t) * (size_t)nRays, hipMemcpyDeviceToHost));
+        if (good && mtState) good = ok(hipMemcpy(mtState, dState, sizeof(uint32_t) * 625 * (size_t)nStreams, hipMemcpyDeviceToHost));
+        if (!good) rc = PVOL_E_NO_DEVICE;
+    }
+    if (dRays) hipFree(dRays);
+    if (dStreams) hipFree(dStreams);
+    if (dOut) hipFree(dOut);
+    if (dDraws) hipFree(dDraws);
+    if (dState) hipFree(dState);
+    return rc;
+}
+
+int pvol_li_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_stream *streams, uint32_t nStreams, int outputKind,
+                  float *out, uint32_t *draws) {
+    if (outputKind != PVOL_OUT_SPECTRAL && outputKind != PVOL_OUT_XYZ) return PVOL_E_INVALID;
+    return host_batch(c, rays, nRays, streams, nStreams, outputKind, out, draws, 0, 0);
+}
+
+int pvol_transmittance_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_stream *streams, uint32_t nStreams, float *out) {
+    return host_batch(c, rays, nRays, streams, nStreams, PVOL_OUT_SPECTRAL, out, 0, 0, 1);
+}
+
+int pvol_li(pvol_ctx *c, const pvol_ray *ray, uint32_t *mt, int32_t *mti, float *Lv, float *T) {
+    if (!c || !ray || !mt || !mti || !Lv || !T) return PVOL_E_INVALID;
+    if (*mti < 0 || *mti > 624) return PVOL_E_INVALID;
+    uint32_t state[625];
+    memcpy(state, mt, sizeof(uint32_t) * 624);
+    state[624] = (uint32_t)*mti;
+    pvol_stream st;
+    memset(&st, 0, sizeof(st));
+    st.n_rays = 1;
+    float out[60];
+    int rc = host_batch(c, ray, 1, &st, 1, PVOL_OUT_SPECTRAL, out, 0, state, 0);
+    if (rc != PVOL_OK) return rc;
+    memcpy(Lv, out, sizeof(float) * 30);
+    memcpy(T, out + 30, sizeof(float) * 30);
+    memcpy(mt, state, sizeof(uint32_t) * 624);
+    *mti = (int32_t)state[624];
+    return PVOL_OK;
+}
+
+int pvol_enable_stats(pvol_ctx *c, int on) {
+    if (!c) return PVOL_E_INVALID;
+    c->statsOn = on != 0;
+    return PVOL_OK;
+}
+
+int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
+    if (!c || !out) return PVOL_E_INVALID;
+    if (!ok(hipSetDevice(c->params.device)) || !ok(hipDeviceSynchronize())) return PVOL_E_NO_DEVICE;
+    DevCounters h;
+    if (!ok(hipMemcpy(&h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost))) return PVOL_E_NO_DEVICE;
+    memset(out, 0, sizeof(*out));
+    out->n_rays = h.nRays; out->n_steps = h.nSteps; out->n_tested = h.nTested; out->n_kept = h.nKept;
+    out->n_lookups_lt10 = h.nLookupsLt10; out->n_shadow_unoccluded = h.nShadowUnoccluded;
+    if (reset && !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) return PVOL_E_NO_DEVICE;
+    return PVOL_OK;
+}
+
+int pvol_kernel_time_ms(pvol_ctx *c, double *avgMs, uint64_t *launches, int reset) {
+    if (!c || !avgMs) return PVOL_E_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    for (auto &p : c->pending) {
+        if (!ok(hipEventSynchronize(p.second))) return PVOL_E_NO_DEVICE;
+        float ms = 0.f;
+        if (ok(hipEventElapsedTime(&ms, p.first, p.second))) { c->timeMs += ms; c->launches += 1; }
+        c->pool.push_back(p);
+    }
+    c->pending.clear();
+    *avgMs = c->launches ? c->timeMs / (double)c->launches : 0.0;
+    if (launches) *launches = c->launches;
+    if (reset) { c->timeMs = 0; c->launches = 0; }
+    return PVOL_OK;
+}
+
+}  // extern "C"

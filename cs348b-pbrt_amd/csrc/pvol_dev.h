@@ -1,0 +1,75 @@
+// pvol_dev.h -- device-side data layout shared by the HIP kernels and the C-ABI host code.
+//
+// Layout in HBM (all fp32 unless noted):
+//   photon map, sorted by grid cell (x fastest), SoA:
+//     pos4  [n]      float4 {x, y, z, original index as bits}   -- 16 B per distance test
+//     alpha [n][32]  30 spectral bins + 2 zero pads = one 128-B row, read as 8 x float4 by an
+//                    8-lane group (rows of photons outside a homogeneous extent are zeroed:
+//                    HomogeneousVolumeDensity::p() returns 0 there, volumes/homogeneous.h:76-79)
+//     wi4   [n]      float4 {wi.x, wi.y, wi.z, 0}               -- only read when g != 0
+//   cellStart [ncells+1] u32: first sorted photon of each cell; a row of cells along x is one
+//     contiguous photon range, so a lookup touches (2R+1)^2 ranges.
+// Spectra live in an "8 lanes x float4" register layout: lane l holds bins 4*(l&7)..4*(l&7)+3;
+// the 8 groups of a wavefront hold copies (or, during the flux sum, 8 different photons).
+#ifndef PVOL_DEV_H
+#define PVOL_DEV_H
+
+#include <stdint.h>
+#include "../../include/pvol.h"
+
+#define PVOL_MAX_LIGHTS 8
+#define PVOL_MAX_TRIS 64
+#define PVOL_MAX_RING 8   // search radius in cells: rings of (dy,dz) rows, 8r rows per ring <= 64 lanes
+
+struct DevLight {
+    int32_t kind;
+    float pos[3];
+    float dir[3];
+    float w2l[12];  // rows 0..2 of WorldToLight (vectors only)
+    float cosTotalWidth, cosFalloffStart;
+    float intensity[32];
+};
+
+struct DevTri {
+    float p1[3], p2[3], p3[3];
+};
+
+struct DevScene {
+    // volume
+    int32_t volKind;
+    float extLo[3], extHi[3];
+    float w2v[16];
+    float sigA[32], sigS[32], le[32];
+    float g;
+    int32_t nx, ny, nz;
+    const float *density;
+    // lights / triangles
+    int32_t nLights;
+    DevLight lights[PVOL_MAX_LIGHTS];
+    int32_t nTris;
+    DevTri tris[PVOL_MAX_TRIS];
+    // colour matching
+    float cieX[32], cieY[32], cieZ[32];
+    // integrator parameters
+    float stepSize, maxDist, maxDistSq;
+    int32_t nUsed;
+    // photon grid
+    uint32_t nPhotons;
+    float gridLo[3];
+    float cellSize, invCell;
+    int32_t gdim[3];
+    int32_t ringMax;          // ceil(maxDist / cellSize), <= PVOL_MAX_RING
+    const uint32_t *cellStart;
+    const float4 *pos4;
+    const float4 *alpha4;     // n * 8 float4
+    const float4 *wi4;
+    // LDS plan (bytes offsets are derived in the kernel from these)
+    int32_t candCap;          // candidate list capacity (multiple of 64, >= nUsed + 128)
+    int32_t maxSteps;         // upper bound of march steps per ray (lightNum array length)
+};
+
+struct DevCounters {
+    unsigned long long nRays, nSteps, nTested, nKept, nLookupsLt10, nShadowUnoccluded, nErrors, pad;
+};
+
+#endif

@@ -1,0 +1,173 @@
+"""ctypes binding of libpvol.so, the C ABI declared in include/pvol.h.
+
+This is plumbing only: every compute call goes to the HIP library, and loading fails loudly when
+the library has not been built (there is no Python or CPU fallback).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpvol.so")
+
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+
+
+class PvolError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        RuntimeError.__init__(self, "%s: %s (%d)" % (where, lib().pvol_strerror(status).decode(), status))
+
+
+_lib = None
+
+
+def lib():
+    """Load libpvol.so (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no fallback path" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.pvol_abi_version.restype = C.c_int
+        L.pvol_strerror.restype = C.c_char_p
+        L.pvol_strerror.argtypes = [C.c_int]
+        L.pvol_device_count.restype = C.c_int
+        L.pvol_default_params.argtypes = [C.POINTER(abi.Params)]
+        L.pvol_default_params.restype = None
+        L.pvol_create.argtypes = [C.POINTER(abi.Params), C.POINTER(C.c_void_p)]
+        L.pvol_destroy.argtypes = [C.c_void_p]
+        L.pvol_destroy.restype = None
+        L.pvol_set_scene.argtypes = [C.c_void_p, C.POINTER(abi.Scene)]
+        L.pvol_upload_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32]
+        L.pvol_preprocess.argtypes = [C.c_void_p, C.c_uint32]
+        L.pvol_photon_count.argtypes = [C.c_void_p, _u32p]
+        L.pvol_download_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32]
+        L.pvol_li_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, _f32p, _u32p]
+        L.pvol_li_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pvol_li.argtypes = [C.c_void_p, C.c_void_p, _u32p, C.POINTER(C.c_int32), _f32p, _f32p]
+        L.pvol_transmittance_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, _f32p]
+        L.pvol_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats), C.c_int]
+        L.pvol_enable_stats.argtypes = [C.c_void_p, C.c_int]
+        L.pvol_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        _lib = L
+    return _lib
+
+
+EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_default_params", "pvol_create",
+           "pvol_destroy", "pvol_set_scene", "pvol_upload_photons", "pvol_preprocess", "pvol_photon_count",
+           "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
+           "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms"]
+
+
+def _check(rc, where):
+    if rc != abi.PVOL_OK:
+        raise PvolError(rc, where)
+
+
+class PhotonVolume:
+    """Host-side mirror of the reference's plugin surface for this path: construct from the
+    integrator/shooter parameters (CreatePhotonVolumeIntegrator / CreatePhotonShooter), hand it the
+    scene, `preprocess()` or `upload_photons()`, then `li()` / `transmittance()`."""
+
+    def __init__(self, params):
+        self._h = C.c_void_p()
+        self.params = params
+        _check(lib().pvol_create(C.byref(params), C.byref(self._h)), "pvol_create")
+        self._scene = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().pvol_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, holder):
+        self._scene = holder  # keeps the ctypes arrays alive
+        _check(lib().pvol_set_scene(self._h, C.byref(holder.scene)), "pvol_set_scene")
+
+    def upload_photons(self, p, wi, alpha):
+        p = np.ascontiguousarray(p, np.float32).reshape(-1)
+        wi = np.ascontiguousarray(wi, np.float32).reshape(-1)
+        alpha = np.ascontiguousarray(alpha, np.float32).reshape(-1)
+        n = p.size // 3
+        if wi.size != 3 * n or alpha.size != 30 * n:
+            raise ValueError("photon arrays disagree: %d positions, %d directions, %d weights" % (n, wi.size // 3, alpha.size // 30))
+        _check(lib().pvol_upload_photons(self._h, p.ctypes.data_as(_f32p), wi.ctypes.data_as(_f32p), alpha.ctypes.data_as(_f32p), n),
+               "pvol_upload_photons")
+
+    def preprocess(self, n_tasks=1):
+        _check(lib().pvol_preprocess(self._h, n_tasks), "pvol_preprocess")
+
+    def photon_count(self):
+        n = C.c_uint32()
+        _check(lib().pvol_photon_count(self._h, C.byref(n)), "pvol_photon_count")
+        return n.value
+
+    def download_photons(self):
+        n = self.photon_count()
+        p = np.zeros((n, 3), np.float32)
+        wi = np.zeros((n, 3), np.float32)
+        alpha = np.zeros((n, 30), np.float32)
+        _check(lib().pvol_download_photons(self._h, p.ctypes.data_as(_f32p), wi.ctypes.data_as(_f32p), alpha.ctypes.data_as(_f32p), n),
+               "pvol_download_photons")
+        return p, wi, alpha
+
+    def li(self, rays, streams, output_kind=abi.OUT_SPECTRAL):
+        """PhotonVolumeIntegrator::Li for a batch; returns (out[n, 60|4], draws[n]); streams['end_draw'] is updated."""
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype == abi.RAY_DTYPE and streams.dtype == abi.STREAM_DTYPE and streams.flags["C_CONTIGUOUS"]
+        n = len(rays)
+        out = np.zeros((n, 60 if output_kind == abi.OUT_SPECTRAL else 4), np.float32)
+        draws = np.zeros(n, np.uint32)
+        _check(lib().pvol_li_batch(self._h, rays.ctypes.data, n, streams.ctypes.data, len(streams), output_kind,
+                                   out.ctypes.data_as(_f32p), draws.ctypes.data_as(_u32p)), "pvol_li_batch")
+        return out, draws
+
+    def li_device(self, d_rays, n_rays, d_streams, n_streams, output_kind, d_out, d_draws=0, hip_stream=0):
+        """Device-pointer variant (integers): enqueue only, no synchronisation."""
+        _check(lib().pvol_li_batch_device(self._h, d_rays, n_rays, d_streams, n_streams, output_kind, d_out, d_draws, hip_stream),
+               "pvol_li_batch_device")
+
+    def li_single(self, ray, mt, mti):
+        """Per-sample shim: ray is a length-1 RAY_DTYPE array, mt a uint32[624] array (updated in place)."""
+        Lv = np.zeros(30, np.float32)
+        T = np.zeros(30, np.float32)
+        i = C.c_int32(int(mti))
+        ray = np.ascontiguousarray(ray)
+        _check(lib().pvol_li(self._h, ray.ctypes.data, mt.ctypes.data_as(_u32p), C.byref(i), Lv.ctypes.data_as(_f32p), T.ctypes.data_as(_f32p)),
+               "pvol_li")
+        return Lv, T, i.value
+
+    def transmittance(self, rays, streams):
+        rays = np.ascontiguousarray(rays)
+        n = len(rays)
+        out = np.zeros((n, 30), np.float32)
+        _check(lib().pvol_transmittance_batch(self._h, rays.ctypes.data, n, streams.ctypes.data, len(streams), out.ctypes.data_as(_f32p)),
+               "pvol_transmittance_batch")
+        return out
+
+    def enable_stats(self, on=True):
+        _check(lib().pvol_enable_stats(self._h, int(on)), "pvol_enable_stats")
+
+    def stats(self, reset=False):
+        s = abi.Stats()
+        _check(lib().pvol_get_stats(self._h, C.byref(s), int(reset)), "pvol_get_stats")
+        return {k: int(getattr(s, k)) for k, _ in abi.Stats._fields_ if k != "reserved"}
+
+    def kernel_time_ms(self, reset=False):
+        avg = C.c_double()
+        n = C.c_uint64()
+        _check(lib().pvol_kernel_time_ms(self._h, C.byref(avg), C.byref(n), int(reset)), "pvol_kernel_time_ms")
+        return avg.value, n.value

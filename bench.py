@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric on MI355X: Msamples/s of the volumetric photon-mapping hot path
+(ray march + k-NN photon gather, PhotonVolumeIntegrator::Li) on config[1]:
+projectScene/volumescene (homogeneous variant) at 1280x720, 256 spp, 1 M volume photons.
+
+One "step" = one pass of the hot path over the whole frame's camera samples (incl. the +-2 px filter
+apron: 1284 x 724 x 256 = 238 M Li() calls), inputs resident in HBM before the timed region.
+N > 1: the reference's render tiles (one MT19937 stream each) are sharded over ranks, photon map
+replicated, no data-path collective; value = samples of all ranks / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import importlib
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def tile_grid(n_tiles, dx, dy):
+    """Sampler::ComputeSubWindow's tile lattice (core/sampler.cpp:55-74)."""
+    nx, ny = n_tiles, 1
+    while (nx & 1) == 0 and 2 * dx * ny < dy * nx:
+        nx >>= 1
+        ny <<= 1
+    return nx, ny
+
+
+def round_up_pow2(v):
+    return 1 << (int(v) - 1).bit_length()
+
+
+def frame_tiles(xres, yres):
+    """The reference's render tiles over the sample extent (film/image.cpp:157-166: pixels +- filter
+    width 2; renderers/samplerrenderer.cpp:206-208 with <= 128 cores; core/sampler.cpp:55-74)."""
+    x_lo, x_hi, y_lo, y_hi = -2, xres + 2, -2, yres + 2
+    n_tiles = round_up_pow2(max(32 * 1, xres * yres // 256))
+    nx, ny = tile_grid(n_tiles, x_hi - x_lo, y_hi - y_lo)
+    tids = np.arange(n_tiles)
+    tx, ty = tids % nx, tids // nx
+    fx = lambda t: np.floor(x_lo + (x_hi - x_lo) * t).astype(np.int64)   # Lerp + Floor2Int, sampler.cpp:66-73
+    fy = lambda t: np.floor(y_lo + (y_hi - y_lo) * t).astype(np.int64)
+    return fx(tx / nx), fx((tx + 1) / nx), fy(ty / ny), fy((ty + 1) / ny), n_tiles
+
+
+def synth_photons(n, seed=348):
+    """Synthetic 1 M-photon map shaped like a real one: the committed 6 k-photon map of this scene
+    (shot by the oracle shooter) resampled with a 0.25-unit Gaussian jitter, flux rescaled."""
+    pkg = importlib.import_module("cs348b-pbrt_amd")
+    b = pkg.blob.load(os.path.join(GOLD, "photons_vh.bin"))
+    P, W, A = b["p"].reshape(-1, 3), b["wi"].reshape(-1, 3), b["alpha"].reshape(-1, 30)
+    rng = np.random.default_rng(seed)
+    idx = rng.integers(0, len(P), n)
+    p = (P[idx] + rng.normal(0, 0.25, (n, 3))).astype(np.float32)
+    lo, hi = np.array([-5, -0.5, -1.5], np.float32), np.array([5, 4.5, 6.5], np.float32)
+    p = np.clip(p, lo + 1e-3, hi - 1e-3)
+    w = W[rng.integers(0, len(P), n)].astype(np.float32)
+    a = (A[idx] * (len(P) / float(n))).astype(np.float32)
+    return p, w, a
+
+
+def build_rays(torch, dev, scene, xres, yres, spp, tiles, seed):
+    """Camera samples for tiles [t0, t1) in the reference's order (tile by tile, pixel by pixel, spp
+    consecutive samples per pixel), as pvol_ray records on the device.  Synthetic jittered samples;
+    rays are clipped at the scene's three quads like SamplerRenderer::Li does before the volume
+    integrator runs (renderers/samplerrenderer.cpp:234)."""
+    x0s, x1s, y0s, y1s = tiles
+    counts = ((x1s - x0s) * (y1s - y0s) * spp).astype(np.int64)
+    total = int(counts.sum())
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    rays = torch.zeros((total, 12), dtype=torch.float32, device=dev)
+    # pixel coordinates per sample, built tile by tile on the device in chunks
+    off = 0
+    tan = math.tan(math.radians(float(scene["camera.fov"][0])) / 2)
+    aspect = xres / float(yres)
+    sx, sy = (aspect, 1.0) if aspect > 1 else (1.0, 1.0 / aspect)
+    chunk = 256
+    for c0 in range(0, len(x0s), chunk):
+        xs, ys = [], []
+        for t in range(c0, min(c0 + chunk, len(x0s))):
+            w, h = int(x1s[t] - x0s[t]), int(y1s[t] - y0s[t])
+            if w <= 0 or h <= 0:
+                continue
+            px = torch.arange(int(x0s[t]), int(x1s[t]), device=dev, dtype=torch.float32)
+            py = torch.arange(int(y0s[t]), int(y1s[t]), device=dev, dtype=torch.float32)
+            gy, gx = torch.meshgrid(py, px, indexing="ij")
+            xs.append(gx.reshape(-1).repeat_interleave(spp))
+            ys.append(gy.reshape(-1).repeat_interleave(spp))
+        if not xs:
+            continue
+        X = torch.cat(xs)
+        Y = torch.cat(ys)
+        n = X.numel()
+        X = X + torch.rand(n, device=dev, generator=g)
+        Y = Y + torch.rand(n, device=dev, generator=g)
+        # perspective camera at the origin looking down +z (cameras/perspective.cpp), fov on the short axis
+        dxn = (2 * X / xres - 1) * sx * tan
+        dyn = (1 - 2 * Y / yres) * sy * tan
+        d = torch.stack([dxn, dyn, torch.ones_like(dxn)], 1)
+        d = d / d.norm(dim=1, keepdim=True)
+        # closest hit with the three quads of volumescene (world space: floor y=-0.5, back z=6.5, side x=5)
+        inf = torch.full((n,), float("inf"), device=dev)
+        t_floor = torch.where(d[:, 1] < 0, -0.5 / d[:, 1], inf)
+        hx, hz = d[:, 0] * t_floor, d[:, 2] * t_floor
+        t_floor = torch.where((hx.abs() <= 5) & (hz >= -1.5) & (hz <= 8.5), t_floor, inf)
+        t_back = 6.5 / d[:, 2]
+        bx, by = d[:, 0] * t_back, d[:, 1] * t_back
+        t_back = torch.where((bx.abs() <= 5) & (by >= -0.5) & (by <= 9.5), t_back, inf)
+        t_side = torch.where(d[:, 0] > 0, 5.0 / d[:, 0], inf)
+        sy_, sz_ = d[:, 1] * t_side, d[:, 2] * t_side
+        t_side = torch.where((sy_ >= -0.5) & (sy_ <= 9.5) & (sz_ >= 0.5) & (sz_ <= 6.5), t_side, inf)
+        maxt = torch.minimum(torch.minimum(t_floor, t_back), t_side)
+        r = rays[off:off + n]
+        r[:, 4:7] = d
+        r[:, 7] = maxt
+        r[:, 9] = torch.rand(n, device=dev, generator=g)   # scatter_u
+        off += n
+    assert off == total
+    return rays, counts
+
+
+def cpu_baseline(scene, params, photons, xres, yres, budget_s=15.0):
+    """The oracle (CPU restatement of the reference path, kd-tree gather) timed on this host's cores
+    on a bounded sample of the SAME workload: whole render tiles of the frame, one thread per core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    pkg = importlib.import_module("cs348b-pbrt_amd")
+    abi = pkg.abi
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    o = orc.Oracle(abi.SceneHolder(scene), params)
+    t0 = time.time()
+    o.set_photons(*photons)
+    t_build = time.time() - t0
+    rng = np.random.default_rng(1)
+    tan = math.tan(math.radians(float(scene["camera.fov"][0])) / 2)
+    aspect = xres / float(yres)
+    per_stream = 64
+    n_streams = cores * 2
+    done, elapsed = 0, 0.0
+    while elapsed < budget_s:
+        n = per_stream * n_streams
+        X, Y = rng.random(n) * xres, rng.random(n) * yres
+        d = np.stack([(2 * X / xres - 1) * aspect * tan, (1 - 2 * Y / yres) * tan, np.ones(n)], 1)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = abi.make_rays(np.zeros((n, 3), np.float32), d.astype(np.float32), 0.0, np.inf, rng.random(n).astype(np.float32))
+        st = abi.make_streams(np.arange(n_streams, dtype=np.uint32), np.full(n_streams, per_stream, np.uint32))
+        t0 = time.time()
+        o.li_batch(rays, st, abi.OUT_XYZ, n_threads=cores)
+        dt = time.time() - t0
+        done += n
+        elapsed += dt
+        if dt < 1.0:
+            per_stream *= 2
+    ctr = o.counters()
+    return {"value": done / elapsed / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d Li() calls (random pixels of the same frame, same scene/photon map/params, kd-tree gather as core/kdtree.h), "
+                      "%.1f s; kd build %.1f s; V=%.0f nodes, K=%.1f photons per lookup" %
+                      (done, elapsed, t_build, ctr["n_nodes_visited"] / max(1, ctr["n_lookups"]), ctr["n_kept"] / max(1, ctr["n_lookups"]))}, ctr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--xres", type=int, default=1280)
+    ap.add_argument("--yres", type=int, default=720)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--photons", type=int, default=1000000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stats", action="store_true", help="collect gather work counters (slower)")
+    ap.add_argument("--cell-scale", type=float, default=0.0, help="photon-grid cell edge multiplier (0 = library default)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    pkg = importlib.import_module("cs348b-pbrt_amd")
+    pvol = importlib.import_module("cs348b-pbrt_amd.pvol")
+    abi, blob = pkg.abi, pkg.blob
+    scene = blob.load(os.path.join(GOLD, "scene_volumescene_h.bin"))
+    params = abi.params_from_blob(scene, n_volume_photons=args.photons, device=local_rank, grid_cell_scale=args.cell_scale)
+    photons = synth_photons(args.photons)
+
+    pv = pvol.PhotonVolume(params)
+    pv.set_scene(abi.SceneHolder(scene))
+    pv.upload_photons(*photons)
+
+    x0s, x1s, y0s, y1s, n_tiles = frame_tiles(args.xres, args.yres)
+    mine = np.arange(rank, n_tiles, world)          # round-robin keeps every rank's tiles spread over the frame
+    tiles = (x0s[mine], x1s[mine], y0s[mine], y1s[mine])
+    rays, counts = build_rays(torch, dev, scene, args.xres, args.yres, args.spp, tiles, seed=1234 + rank)
+    n_rays = int(counts.sum())
+    st = abi.make_streams(mine.astype(np.uint32), counts.astype(np.uint32))   # RNG(taskNum), samplerrenderer.cpp:73
+    d_streams = torch.from_numpy(st.view(np.uint8).reshape(len(st), 32).copy()).to(dev)
+    d_out = torch.zeros((n_rays, 4), dtype=torch.float32, device=dev)
+    if args.stats:
+        pv.enable_stats(True)
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        pv.li_device(rays.data_ptr(), n_rays, d_streams.data_ptr(), len(st), abi.OUT_XYZ, d_out.data_ptr(), 0, stream)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    pv.kernel_time_ms(reset=True)
+    if args.stats:
+        pv.stats(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([n_rays], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_rays = int(tot.item())
+    else:
+        total_rays = n_rays
+    kms, launches = pv.kernel_time_ms()
+    checksum = float(d_out[:, :3].double().sum().item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_rays * args.steps / dt / 1e6
+        res = {
+            "metric": "volumetric photon-gather throughput (camera samples through PhotonVolumeIntegrator::Li per second)",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "volumescene (homogeneous) %dx%d, %d spp, %d volume photons, nused %d, maxdist %.2f, stepsize %.2f; "
+                                   "%d render tiles (MT19937 streams), %d Li() calls per step incl. filter apron" %
+                                   (args.xres, args.yres, args.spp, args.photons, params.n_used, params.max_dist, params.step_size,
+                                    n_tiles, total_rays),
+                       "photon_map": "synthetic: 6k-photon oracle-shot map of the same scene resampled to %d" % args.photons,
+                       "partition": "tiles round-robin over %d rank(s), photon map replicated, no data-path collective" % world},
+            "wall_s": dt, "checksum_xyz": checksum,
+        }
+        # roofline of the dominant kernel (li_kernel): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
+        cpu, ctr = (None, None)
+        if not args.no_cpu_baseline:
+            cpu, ctr = cpu_baseline(scene, params, photons, args.xres, args.yres)
+            res["cpu_baseline"] = cpu
+        stats = pv.stats() if args.stats else None
+        V = (ctr["n_nodes_visited"] / max(1, ctr["n_lookups"])) if ctr else 323.0
+        K = (ctr["n_kept"] / max(1, ctr["n_lookups"])) if ctr else 50.0
+        steps_per_ray = (ctr["n_steps"] / max(1, ctr["n_rays"])) if ctr else 33.8
+        b_lookup = 20.0 * V + 132.0 * K
+        bytes_per_launch = b_lookup * steps_per_ray * n_rays + 16.0 * n_rays + 48.0 * n_rays
+        achieved = bytes_per_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                           "traffic": None,
+                           "kernel": "li_kernel", "kernel_avg_ms": kms, "kernel_launches": launches,
+                           "algorithmic_bytes_per_lookup": b_lookup, "V": V, "K": K, "lookups_per_sample": steps_per_ray,
+                           "note": "B_lookup = 20*V + 132*K with V, K from the reference-algorithm counters of the CPU baseline on the same inputs"}
+        if stats:
+            res["gpu_counters"] = stats
+        print(json.dumps(res))
+    pv.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

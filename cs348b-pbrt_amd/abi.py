@@ -82,7 +82,9 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("n_rays", C.c_uint64), ("n_steps", C.c_uint64), ("n_tested", C.c_uint64),
                 ("n_kept", C.c_uint64), ("n_lookups_lt10", C.c_uint64),
-                ("n_shadow_unoccluded", C.c_uint64), ("reserved", C.c_uint64 * 2)]
+                ("n_shadow_unoccluded", C.c_uint64), ("n_guess_retries", C.c_uint64),
+                ("cy_search", C.c_uint64), ("cy_select", C.c_uint64), ("cy_flux", C.c_uint64),
+                ("cy_total", C.c_uint64), ("reserved", C.c_uint64 * 3)]
 
 
 # numpy views of the two array-of-struct inputs (sizes checked against pvol.h in the tests)

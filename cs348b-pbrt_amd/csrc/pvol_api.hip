@@ -18,6 +18,7 @@ struct LiArgs {
     const pvol_ray *rays;
     pvol_stream *streams;
     uint32_t nStreams;
+    uint32_t nRays;
     int outputKind;
     float *out;
     uint32_t *draws;
@@ -25,6 +26,9 @@ struct LiArgs {
     uint32_t *finalState;
     DevCounters *counters;
     int transmittanceOnly;
+    uint32_t *chunkCounter;
+    uint32_t *needSeq;
+    int gated;
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
@@ -36,7 +40,8 @@ struct GridBuildArgs {
     float extLo[3], extHi[3];
     float w2v[16];
 };
-extern "C" hipError_t pvol_launch_li(const LiArgs *args, size_t ldsBytes, bool stats, hipStream_t stream);
+extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
+extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
                                       uint32_t *cellStart, hipStream_t stream);
 
@@ -52,6 +57,9 @@ struct pvol_ctx {
     float4 *dPos4, *dAlpha4, *dWi4;
     uint32_t *dCellStart;
     DevCounters *dCounters;
+    uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
+    int nCU;
+    bool forceSeq;      // PVOL_FORCE_SEQ=1: always take the stream-sequential kernel (testing)
     bool statsOn;
     // kernel timing (HIP events on the launch stream)
     std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;
@@ -106,6 +114,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     if (!params || !out) return PVOL_E_INVALID;
     *out = 0;
     if (params->n_used < 1 || !(params->step_size > 0.f) || !(params->max_dist > 0.f)) return PVOL_E_INVALID;
+    if (params->n_used > 576) return PVOL_E_UNSUPPORTED;   // select_k holds the candidate list in 12 registers per lane
     int n = 0;
     if (!ok(hipGetDeviceCount(&n)) || n <= 0 || params->device < 0 || params->device >= n) return PVOL_E_NO_DEVICE;
     if (!ok(hipSetDevice(params->device))) return PVOL_E_NO_DEVICE;
@@ -120,12 +129,17 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     c->dPos4 = c->dAlpha4 = c->dWi4 = 0;
     c->dCellStart = 0;
     c->dCounters = 0;
+    c->dWords = 0;
+    c->nCU = 256;
+    { const char *fs = getenv("PVOL_FORCE_SEQ"); c->forceSeq = fs && fs[0] == '1'; }
+    { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
-    if (!ok(hipMalloc(&c->ds, sizeof(DevScene))) || !ok(hipMalloc(&c->dCounters, sizeof(DevCounters))) ||
+    if (!ok(hipMalloc(&c->ds, sizeof(DevScene))) || !ok(hipMalloc(&c->dCounters, sizeof(DevCounters))) || !ok(hipMalloc(&c->dWords, 16)) ||
         !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) {
         if (c->ds) hipFree(c->ds);
         if (c->dCounters) hipFree(c->dCounters);
+        if (c->dWords) hipFree(c->dWords);
         delete c;
         return PVOL_E_NO_DEVICE;
     }
@@ -157,6 +171,7 @@ void pvol_destroy(pvol_ctx *c) {
     if (c->dDensity) hipFree(c->dDensity);
     if (c->ds) hipFree(c->ds);
     if (c->dCounters) hipFree(c->dCounters);
+    if (c->dWords) hipFree(c->dWords);
     delete c;
 }
 
@@ -246,7 +261,7 @@ static void choose_grid(pvol_ctx *c, const float *p, uint32_t n) {
     const float maxDist = c->params.max_dist;
     for (int a = 0; a < 3; ++a) { ext[a] = std::max((double)hi[a] - lo[a], 1e-3 * maxDist); vol *= ext[a]; }
     // aim at ~4 photons per cell, never more than PVOL_MAX_RING rings per lookup, at most 2^24 cells
-    double cell = cbrt(vol * 4.0 / std::max(1u, n));
+    double cell = cbrt(vol * 1.4 / std::max(1u, n));   // ~1.4 photons per cell measured best on MI355X (profiles/)
     if (c->params.grid_cell_scale > 0.f) cell *= c->params.grid_cell_scale;
     cell = std::max(cell, (double)maxDist / PVOL_MAX_RING * 1.0001);
     for (;;) {
@@ -323,22 +338,42 @@ int pvol_download_photons(pvol_ctx *c, float *p, float *wi, float *alpha, uint32
     return good ? PVOL_OK : PVOL_E_NO_DEVICE;
 }
 
-static size_t lds_bytes(const pvol_ctx *c) { return 624 * 4 + (size_t)c->hs.candCap * 8 + (size_t)c->hs.maxSteps * 4; }
+// LDS plans of the two kernels (pvol_march.hip)
+static size_t lds_bytes_seq(const pvol_ctx *c) { return 624 * 4 + (size_t)c->hs.candCap * 8 + (size_t)c->hs.maxSteps * 4 + 256 * 4; }
+static size_t lds_bytes_par(const pvol_ctx *c) { return (size_t)c->hs.candCap * 8 + 256 * 4; }
 
-static int launch(pvol_ctx *c, const pvol_ray *dRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind, float *dOut,
-                  uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, hipStream_t stream) {
+// Drawn VALUES cannot reach Li()'s result with at most one light and an analytic tau():
+// such scenes take the ray-parallel kernel, backed by the sequential one if a ray reaches the roulette.
+static bool par_eligible(const pvol_ctx *c) { return c->hs.nLights <= 1 && c->hs.volKind != PVOL_VOLUME_GRID; }
+
+static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
+                  float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, hipStream_t stream) {
     LiArgs a;
-    a.scene = c->ds; a.rays = dRays; a.streams = dStreams; a.nStreams = nStreams; a.outputKind = outputKind;
+    a.scene = c->ds; a.rays = dRays; a.streams = dStreams; a.nStreams = nStreams; a.nRays = nRays; a.outputKind = outputKind;
     a.out = dOut; a.draws = dDraws; a.initState = dInit; a.finalState = dFinal; a.counters = c->dCounters;
     a.transmittanceOnly = transOnly;
+    a.chunkCounter = c->dWords; a.needSeq = c->dWords + 1; a.gated = 0;
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
         std::lock_guard<std::mutex> g(c->mu);
         if (!c->pool.empty()) { ev = c->pool.back(); c->pool.pop_back(); }
         else if (!ok(hipEventCreate(&ev.first)) || !ok(hipEventCreate(&ev.second))) return PVOL_E_NO_DEVICE;
     }
+    hipError_t e;
+    const bool par = par_eligible(c) && !dInit && !c->forceSeq;
+    if (par) hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
     hipEventRecord(ev.first, stream);
-    hipError_t e = pvol_launch_li(&a, lds_bytes(c), c->statsOn, stream);
+    if (par) {
+        unsigned long long chunks = ((unsigned long long)nRays + 63ull) / 64ull;
+        uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
+        e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
+        if (ok(e)) {   // runs only if a ray raised needSeq (gate read on the device: no host sync here)
+            a.gated = 1;
+            e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
+        }
+    } else {
+        e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
+    }
     hipEventRecord(ev.second, stream);
     {
         std::lock_guard<std::mutex> g(c->mu);
@@ -353,7 +388,7 @@ int pvol_li_batch_device(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvo
     if (outputKind != PVOL_OUT_SPECTRAL && outputKind != PVOL_OUT_XYZ) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
     if (!nStreams) return PVOL_OK;
-    return launch(c, dRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, (hipStream_t)hipStream);
+    return launch(c, dRays, nRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, (hipStream_t)hipStream);
 }
 
 static int check_errors(pvol_ctx *c) {
@@ -372,8 +407,14 @@ static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_st
     if (!c || (nRays && (!rays || !out)) || (nStreams && !streams)) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
-    for (uint32_t s = 0; s < nStreams; ++s)
-        if ((uint64_t)streams[s].first_ray + streams[s].n_rays > nRays) return PVOL_E_INVALID;
+    {   // streams must partition the ray array in order (every ray belongs to exactly one stream)
+        uint64_t next = 0;
+        for (uint32_t s = 0; s < nStreams; ++s) {
+            if (streams[s].first_ray != next) return PVOL_E_INVALID;
+            next += streams[s].n_rays;
+        }
+        if (next != nRays) return PVOL_E_INVALID;
+    }
     if (!nStreams || !nRays) return PVOL_OK;
     const size_t width = transOnly ? 60 : (outputKind == PVOL_OUT_SPECTRAL ? 60 : 4);
     pvol_ray *dRays = 0; pvol_stream *dStreams = 0; float *dOut = 0; uint32_t *dDraws = 0, *dState = 0;
@@ -389,7 +430,7 @@ static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_st
         if (good && mtState) good = ok(hipMemcpy(dState, mtState, sizeof(uint32_t) * 625 * (size_t)nStreams, hipMemcpyHostToDevice));
         if (!good) rc = PVOL_E_NO_DEVICE;
     }
-    if (rc == PVOL_OK) rc = launch(c, dRays, dStreams, nStreams, transOnly ? PVOL_OUT_SPECTRAL : outputKind, dOut, dDraws, dState, dState, transOnly, 0);
+    if (rc == PVOL_OK) rc = launch(c, dRays, nRays, dStreams, nStreams, transOnly ? PVOL_OUT_SPECTRAL : outputKind, dOut, dDraws, dState, dState, transOnly, 0);
     if (rc == PVOL_OK && !ok(hipDeviceSynchronize())) rc = PVOL_E_NO_DEVICE;
     if (rc == PVOL_OK) rc = check_errors(c);
     if (rc == PVOL_OK) {
@@ -457,6 +498,8 @@ int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
     memset(out, 0, sizeof(*out));
     out->n_rays = h.nRays; out->n_steps = h.nSteps; out->n_tested = h.nTested; out->n_kept = h.nKept;
     out->n_lookups_lt10 = h.nLookupsLt10; out->n_shadow_unoccluded = h.nShadowUnoccluded;
+    out->n_guess_retries = h.pad;
+    out->cy_search = h.cySearch; out->cy_select = h.cySelect; out->cy_flux = h.cyFlux; out->cy_total = h.cyTotal;
     if (reset && !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) return PVOL_E_NO_DEVICE;
     return PVOL_OK;
 }

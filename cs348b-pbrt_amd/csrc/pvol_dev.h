@@ -70,6 +70,7 @@ struct DevScene {
 
 struct DevCounters {
     unsigned long long nRays, nSteps, nTested, nKept, nLookupsLt10, nShadowUnoccluded, nErrors, pad;
+    unsigned long long cySearch, cySelect, cyFlux, cyTotal;  // s_memtime cycles summed over waves (stats build only)
 };
 
 #endif

@@ -1,0 +1,275 @@
+// pvol_math.h -- device-side value layer of the hot path: float4 spectra, fp32 geometry in the
+// reference's evaluation order, volume / phase / rainbow evaluation.  Included by the HIP kernels only.
+#ifndef PVOL_MATH_H
+#define PVOL_MATH_H
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "pvol_dev.h"
+
+#define LANES 64
+#define MT_N 624
+#define MT_M 397
+#define K_PI 3.14159265358979323846f  /* core/pbrt.h:191: M_PI is a float literal */
+
+typedef float4 f4;
+
+// ------------------------------------------------------------------------------------------ float4 spectra
+__device__ __forceinline__ f4 mk4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ f4 operator+(f4 a, f4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ f4 operator-(f4 a, f4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ f4 operator*(f4 a, f4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ f4 operator/(f4 a, f4 b) { return make_float4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w); }
+__device__ __forceinline__ f4 operator*(f4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ f4 operator/(f4 a, float s) { return make_float4(a.x / s, a.y / s, a.z / s, a.w / s); }
+__device__ __forceinline__ f4 neg4(f4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+// Exp(-tau) per bin (core/spectrum.h:227-233).  __expf = v_exp_f32(x * log2 e): ~1e-6 relative for the
+// optical depths met here, two instructions instead of ~15; only radiance VALUES pass through it (the
+// parity budget is 1e-4 relative L2), never a geometric decision.
+__device__ __forceinline__ f4 exp4(f4 a) { return make_float4(__expf(a.x), __expf(a.y), __expf(a.z), __expf(a.w)); }
+// per-bin divide of radiance values by v_rcp_f32 + multiply (~1 ulp)
+__device__ __forceinline__ f4 fdiv4(f4 a, f4 b) {
+    return make_float4(__fdividef(a.x, b.x), __fdividef(a.y, b.y), __fdividef(a.z, b.z), __fdividef(a.w, b.w));
+}
+// bins 30,31 are padding: force them back to 0 after an operation that could make them non-finite
+__device__ __forceinline__ f4 clean4(f4 a, int q) { if (q == 7) { a.z = 0.f; a.w = 0.f; } return a; }
+__device__ __forceinline__ f4 ld4(const float *base32, int q) { return *reinterpret_cast<const f4 *>(base32 + 4 * q); }
+
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    return v;
+}
+__device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
+__device__ __forceinline__ float wave_max(float v) {
+    for (int m = 1; m < LANES; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
+    return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+// SampledSpectrum::y() (core/spectrum.h:433-439); summation order differs from the scalar loop.
+__device__ __forceinline__ float spec_y(f4 c, f4 Y) {
+    float p = Y.x * c.x + Y.y * c.y + Y.z * c.z + Y.w * c.w;
+    p = group8_sum(p);
+    return p * 300.f / (106.856895f * 30);
+}
+__device__ __forceinline__ bool spec_is_black(f4 c) { return !wave_any(c.x != 0.f || c.y != 0.f || c.z != 0.f || c.w != 0.f); }
+
+// core/montecarlo.h:277-286
+__device__ __forceinline__ float van_der_corput(uint32_t n, uint32_t scramble) {
+    n = __brev(n);
+    n ^= scramble;
+    return fminf(((n >> 8) & 0xffffff) / float(1 << 24), 0x1.fffffep-1f);
+}
+
+// ------------------------------------------------------------------------------------------ geometry
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float f) { return v3(a.x * f, a.y * f, a.z * f); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 vdiv(V3 a, float f) { float inv = 1.f / f; return v3(a.x * inv, a.y * inv, a.z * inv); }  // geometry.h:94-98
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float len_sq(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+__device__ __forceinline__ float len(V3 a) { return sqrtf(len_sq(a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return vdiv(a, len(a)); }
+// core/geometry.h:477-484: double products, one rounding
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    double ax = a.x, ay = a.y, az = a.z, bx = b.x, by = b.y, bz = b.z;
+    return v3(float((ay * bz) - (az * by)), float((az * bx) - (ax * bz)), float((ax * by) - (ay * bx)));
+}
+__device__ __forceinline__ V3 xform_point(const float *m, V3 p) {  // core/transform.h:187-201
+    float xp = m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3];
+    float yp = m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7];
+    float zp = m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11];
+    float wp = m[12] * p.x + m[13] * p.y + m[14] * p.z + m[15];
+    if (wp == 1.f) return v3(xp, yp, zp);
+    float inv = 1.f / wp;
+    return v3(inv * xp, inv * yp, inv * zp);
+}
+__device__ __forceinline__ V3 xform_vector(const float *m, V3 v) {  // core/transform.h:220-226
+    return v3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+struct RayD { V3 o, d; float mint, maxt; };
+
+// BBox::IntersectP, core/geometry.cpp:68-86
+__device__ __forceinline__ bool box_intersect(const float *lo, const float *hi, V3 o, V3 d, float mint, float maxt, float *h0, float *h1) {
+    float t0 = mint, t1 = maxt;
+    const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float inv = 1.f / dd[i];
+        float tn = (lo[i] - oo[i]) * inv;
+        float tf = (hi[i] - oo[i]) * inv;
+        if (tn > tf) { float t = tn; tn = tf; tf = t; }
+        t0 = tn > t0 ? tn : t0;
+        t1 = tf < t1 ? tf : t1;
+        if (t0 > t1) return false;
+    }
+    *h0 = t0;
+    *h1 = t1;
+    return true;
+}
+__device__ __forceinline__ bool box_inside(const float *lo, const float *hi, V3 p) {  // geometry.h:404-408
+    return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];
+}
+// VolumeRegion::IntersectP (volumes/homogeneous.h:60-63, volumegrid.h:52-55)
+__device__ __forceinline__ bool vol_intersect(const DevScene &S, const RayD &r, float *t0, float *t1) {
+    V3 o = xform_point(S.w2v, r.o), d = xform_vector(S.w2v, r.d);
+    return box_intersect(S.extLo, S.extHi, o, d, r.mint, r.maxt, t0, t1);
+}
+// shapes/trianglemesh.cpp:211-243 (any hit) for one triangle
+__device__ __forceinline__ bool tri_hit(const DevTri &tr, const RayD &ray) {
+    V3 p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]), p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+    V3 e1 = p2 - p1, e2 = p3 - p1;
+    V3 s1 = cross(ray.d, e2);
+    float divisor = dot(s1, e1);
+    if (divisor == 0.f) return false;
+    float invDivisor = 1.f / divisor;
+    V3 s = ray.o - p1;
+    float b1 = dot(s, s1) * invDivisor;
+    if (b1 < 0.f || b1 > 1.f) return false;
+    V3 s2 = cross(s, e1);
+    float b2 = dot(ray.d, s2) * invDivisor;
+    if (b2 < 0.f || b1 + b2 > 1.f) return false;
+    float t = dot(e2, s2) * invDivisor;
+    if (t < ray.mint || t > ray.maxt) return false;
+    return true;
+}
+// Scene::IntersectP (core/scene.h:57-61): one triangle per lane
+__device__ __forceinline__ bool scene_occluded(const DevScene &S, const RayD &ray, int lane) {
+    bool hit = false;
+    for (int base = 0; base < S.nTris; base += LANES) {
+        int t = base + lane;
+        bool h = (t < S.nTris) && tri_hit(S.tris[t], ray);
+        hit = hit || wave_any(h);
+    }
+    return hit;
+}
+
+// ------------------------------------------------------------------------------------------ volume
+__device__ __forceinline__ float lerpf(float t, float a, float b) { return (1.f - t) * a + t * b; }
+__device__ __forceinline__ float grid_D(const DevScene &S, int x, int y, int z) {  // volumegrid.h:60-65
+    x = min(max(x, 0), S.nx - 1);
+    y = min(max(y, 0), S.ny - 1);
+    z = min(max(z, 0), S.nz - 1);
+    return S.density[(size_t)z * S.nx * S.ny + (size_t)y * S.nx + x];
+}
+// VolumeGridDensity::Density, volumes/volumegrid.cpp:39-57
+__device__ float grid_density(const DevScene &S, V3 Pobj) {
+    if (!box_inside(S.extLo, S.extHi, Pobj)) return 0.f;
+    float vx_ = (Pobj.x - S.extLo[0]) / (S.extHi[0] - S.extLo[0]);
+    float vy_ = (Pobj.y - S.extLo[1]) / (S.extHi[1] - S.extLo[1]);
+    float vz_ = (Pobj.z - S.extLo[2]) / (S.extHi[2] - S.extLo[2]);
+    vx_ = vx_ * S.nx - .5f;
+    vy_ = vy_ * S.ny - .5f;
+    vz_ = vz_ * S.nz - .5f;
+    int vx = (int)floorf(vx_), vy = (int)floorf(vy_), vz = (int)floorf(vz_);
+    float dx = vx_ - vx, dy = vy_ - vy, dz = vz_ - vz;
+    float d00 = lerpf(dx, grid_D(S, vx, vy, vz), grid_D(S, vx + 1, vy, vz));
+    float d10 = lerpf(dx, grid_D(S, vx, vy + 1, vz), grid_D(S, vx + 1, vy + 1, vz));
+    float d01 = lerpf(dx, grid_D(S, vx, vy, vz + 1), grid_D(S, vx + 1, vy, vz + 1));
+    float d11 = lerpf(dx, grid_D(S, vx, vy + 1, vz + 1), grid_D(S, vx + 1, vy + 1, vz + 1));
+    float d0 = lerpf(dy, d00, d10);
+    float d1 = lerpf(dy, d01, d11);
+    return lerpf(dz, d0, d1);
+}
+// density factor of sigma_a/sigma_s/sigma_t/Lve at a world point: homogeneous.h:64-75 (Inside ? 1 : 0),
+// core/volume.h:81-92 (Density)
+__device__ __forceinline__ float vol_density(const DevScene &S, V3 p) {
+    V3 q = xform_point(S.w2v, p);
+    if (S.volKind == PVOL_VOLUME_GRID) return grid_density(S, q);
+    return box_inside(S.extLo, S.extHi, q) ? 1.f : 0.f;
+}
+// HG phase (core/volume.cpp:150-154); homogeneous p() also tests Inside (homogeneous.h:76-79)
+__device__ __forceinline__ float phase_hg(V3 w, V3 wp, float g) {
+    // g == 0: (1 - 0) / powf(1, 1.5f) is exactly 1, so the reference's value is 1/(4 pi) bit for bit
+    if (g == 0.f) return 1.f / (4.f * K_PI);
+    float costheta = dot(w, wp);
+    return 1.f / (4.f * K_PI) * (1.f - g * g) / powf(1.f + g * g - 2.f * g * costheta, 1.5f);
+}
+__device__ __forceinline__ float vol_phase(const DevScene &S, V3 p, V3 wi, V3 wo) {
+    if (S.volKind != PVOL_VOLUME_GRID && !box_inside(S.extLo, S.extHi, xform_point(S.w2v, p))) return 0.f;
+    return phase_hg(wi, wo, S.g);
+}
+// tau(): homogeneous.h:80-84 analytic; DensityRegion::tau core/volume.cpp:296-310 stepped.
+__device__ f4 vol_tau(const DevScene &S, const RayD &r, float stepSize, float u, f4 sigT) {
+    if (S.volKind != PVOL_VOLUME_GRID) {
+        float t0, t1;
+        if (!vol_intersect(S, r, &t0, &t1)) return mk4(0.f);
+        V3 a = r.o + r.d * t0, b = r.o + r.d * t1;
+        return sigT * len(a - b);
+    }
+    float t0, t1;
+    float length = len(r.d);
+    if (length == 0.f) return mk4(0.f);
+    RayD rn;
+    rn.o = r.o; rn.d = vdiv(r.d, length); rn.mint = r.mint * length; rn.maxt = r.maxt * length;
+    if (!vol_intersect(S, rn, &t0, &t1)) return mk4(0.f);
+    f4 tau = mk4(0.f);
+    t0 += u * stepSize;
+    while (t0 < t1) {
+        tau = tau + sigT * vol_density(S, rn.o + rn.d * t0);
+        t0 += stepSize;
+    }
+    return tau * stepSize;
+}
+
+// volumes/rainbow.cpp:41-78 in the float4 layout
+__device__ __forceinline__ float lerp_or_zero(float theta, float minT, float maxT, float sw, float ew) {
+    if (theta < minT || maxT < theta) return 0;
+    const float thetaRange = maxT - minT;
+    const float wavelengthRange = ew - sw;
+    return sw + (theta - minT) * wavelengthRange / thetaRange;
+}
+__device__ __forceinline__ float lerp_transfer(float x, float xMin, float xMax, float y0, float y1) {
+    if (x < xMin) return y0;
+    if (xMax < x) return y1;
+    const float thetaRange = xMax - xMin;
+    const float range = y1 - y0;
+    return y0 + (x - xMin) * range / thetaRange;
+}
+__device__ f4 rainbow_reflection(f4 spectrum, V3 w, V3 wi, int q) {
+    float cosTheta = dot(wi, -w);
+    const float radToDeg = 57.2957;
+    float theta = radToDeg * acosf(cosTheta);
+    float I = (0.5f + 4.5f * powf(0.5 * (1.f + dot(wi, -w)), 8.f)) / (4.f * K_PI);  // PhaseMieHazy core/volume.cpp:138-141
+    float innerGlow = lerp_transfer(theta, 40.4, 40.45, 1.0, 0.9);
+    I *= innerGlow;
+    float rainbowI = 1.0f;
+    float primaryRainbowI = 0.92f;
+    float secondaryRainbowI = 0.42 * primaryRainbowI;
+    float mistI = 0.08f;
+    float lambda = lerp_or_zero(theta, 40.4, 42.3, 400.0, 700.0);
+    if (lambda) {
+        rainbowI *= primaryRainbowI;
+    } else {
+        lambda = lerp_or_zero(theta, 51.0, 54.4, 700.0, 400.0);
+        if (lambda) rainbowI *= secondaryRainbowI;
+    }
+    if (!lambda) return spectrum * (I * mistI);   // I * mistI * spectrum
+    // CoefficientSpectrum::filter, core/spectrum.h:300-320
+    float deltaLambda = float(700 - 400) / 30;
+    float indexWithDecimals = (lambda - 400) / deltaLambda;
+    int index = int(indexWithDecimals);
+    float t = indexWithDecimals - index;
+    float sp[4] = {spectrum.x, spectrum.y, spectrum.z, spectrum.w};
+    float rb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int bin = 4 * q + c;
+        float v = 0.f;
+        if (index >= 0 && index < 30) {
+            if (bin == index) v = sp[c] * t;
+            if (bin == index + 1 && index + 1 < 30) v = sp[c] * (1 - t);
+        }
+        rb[c] = v;
+    }
+    f4 rainbow = make_float4(rb[0], rb[1], rb[2], rb[3]);
+    return (spectrum * mistI + rainbow * rainbowI) * I;
+}
+
+#endif

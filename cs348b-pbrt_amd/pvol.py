@@ -11,7 +11,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpvol.so")
+LIB_PATH = os.environ.get("PVOL_LIB") or os.path.join(_HERE, "libpvol.so")  # PVOL_LIB: A/B builds of the same ABI
 
 _f32p = C.POINTER(C.c_float)
 _u32p = C.POINTER(C.c_uint32)
@@ -164,7 +164,8 @@ class PhotonVolume:
     def stats(self, reset=False):
         s = abi.Stats()
         _check(lib().pvol_get_stats(self._h, C.byref(s), int(reset)), "pvol_get_stats")
-        return {k: int(getattr(s, k)) for k, _ in abi.Stats._fields_ if k != "reserved"}
+        d = {k: int(getattr(s, k)) for k, _ in abi.Stats._fields_ if k != "reserved"}
+        return d
 
     def kernel_time_ms(self, reset=False):
         avg = C.c_double()

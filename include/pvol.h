@@ -170,7 +170,12 @@ typedef struct pvol_stats {
     uint64_t n_kept;           /* photons that entered a flux sum                         */
     uint64_t n_lookups_lt10;   /* lookups that found < 10 photons (photonvolume.cpp:83)   */
     uint64_t n_shadow_unoccluded;
-    uint64_t reserved[2];
+    uint64_t n_guess_retries;  /* lookups whose predicted radius held < k photons and were redone at maxdist */
+    uint64_t cy_search;        /* s_memtime cycles summed over wavefronts: candidate search ...          */
+    uint64_t cy_select;        /* ... k-selection ...                                                     */
+    uint64_t cy_flux;          /* ... flux sum ...                                                        */
+    uint64_t cy_total;         /* ... whole kernel                                                        */
+    uint64_t reserved[3];
 } pvol_stats;
 
 typedef struct pvol_ctx pvol_ctx;

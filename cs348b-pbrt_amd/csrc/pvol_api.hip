@@ -12,62 +12,7 @@
 
 #include "pvol_dev.h"
 
-// ---- kernels' host entry points (pvol_march.hip, pvol_grid.hip)
-struct LiArgs {
-    const DevScene *scene;
-    const pvol_ray *rays;
-    pvol_stream *streams;
-    uint32_t nStreams;
-    uint32_t nRays;
-    int outputKind;
-    float *out;
-    uint32_t *draws;
-    const uint32_t *initState;
-    uint32_t *finalState;
-    DevCounters *counters;
-    int transmittanceOnly;
-    uint32_t *chunkCounter;
-    uint32_t *needSeq;
-    int gated;
-};
-struct GridBuildArgs {
-    const float *p, *wi, *alpha;
-    uint32_t n;
-    float lo[3];
-    float inv;
-    int32_t gdim[3];
-    int32_t volKind;
-    float extLo[3], extHi[3];
-    float w2v[16];
-};
-extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
-extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
-extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
-                                      uint32_t *cellStart, hipStream_t stream);
-
-struct pvol_ctx {
-    pvol_params params;
-    bool haveScene;
-    DevScene hs;         // host copy
-    DevScene *ds;        // device copy
-    float *dDensity;
-    // photon map
-    uint32_t nPhotons;
-    float *dRawP, *dRawWi, *dRawAlpha;  // upload order (kept for pvol_download_photons)
-    float4 *dPos4, *dAlpha4, *dWi4;
-    uint32_t *dCellStart;
-    DevCounters *dCounters;
-    uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
-    int nCU;
-    bool forceSeq;      // PVOL_FORCE_SEQ=1: always take the stream-sequential kernel (testing)
-    bool statsOn;
-    // kernel timing (HIP events on the launch stream)
-    std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;
-    std::vector<std::pair<hipEvent_t, hipEvent_t> > pool;
-    double timeMs;
-    uint64_t launches;
-    std::mutex mu;
-};
+#include "pvol_host.h"
 
 static bool ok(hipError_t e) { return e == hipSuccess; }
 
@@ -135,9 +80,13 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
+    c->dsh = 0;
+    memset(&c->hsh, 0, sizeof(c->hsh));
+    memset(c->shootStats, 0, sizeof(c->shootStats));
     if (!ok(hipMalloc(&c->ds, sizeof(DevScene))) || !ok(hipMalloc(&c->dCounters, sizeof(DevCounters))) || !ok(hipMalloc(&c->dWords, 16)) ||
-        !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) {
+        !ok(hipMalloc(&c->dsh, sizeof(DevShootScene))) || !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) {
         if (c->ds) hipFree(c->ds);
+        if (c->dsh) hipFree(c->dsh);
         if (c->dCounters) hipFree(c->dCounters);
         if (c->dWords) hipFree(c->dWords);
         delete c;
@@ -147,7 +96,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     return PVOL_OK;
 }
 
-static void free_photons(pvol_ctx *c) {
+void pvol_free_photons(pvol_ctx *c) {
     if (c->dRawP) hipFree(c->dRawP);
     if (c->dRawWi) hipFree(c->dRawWi);
     if (c->dRawAlpha) hipFree(c->dRawAlpha);
@@ -165,14 +114,91 @@ void pvol_destroy(pvol_ctx *c) {
     if (!c) return;
     hipSetDevice(c->params.device);
     hipDeviceSynchronize();
-    free_photons(c);
+    pvol_free_photons(c);
     for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->dDensity) hipFree(c->dDensity);
     if (c->ds) hipFree(c->ds);
+    if (c->dsh) hipFree(c->dsh);
     if (c->dCounters) hipFree(c->dCounters);
     if (c->dWords) hipFree(c->dWords);
     delete c;
+}
+
+// ---- host evaluation of the light-power CDF (ComputeLightSamplingCDF core/integrator.cpp:261-268,
+// Distribution1D montecarlo.h:56-76), fp32 in the reference's order (this file is built with
+// -ffp-contract=off)
+static float host_spec_y(const pvol_scene *s, const float *c30) {
+    float yy = 0.f;
+    for (int i = 0; i < 30; ++i) yy += s->cie_y.c[i] * c30[i];
+    return yy * float(700 - 400) / float(106.856895f * 30);
+}
+static void world_sphere(const pvol_scene *s, float c[3], float *rad) {   // BBox::BoundingSphere, core/geometry.cpp:60-63
+    bool inside = true;
+    for (int a = 0; a < 3; ++a) {
+        c[a] = .5f * s->world_min[a] + .5f * s->world_max[a];
+        inside = inside && c[a] >= s->world_min[a] && c[a] <= s->world_max[a];
+    }
+    float dx = c[0] - s->world_max[0], dy = c[1] - s->world_max[1], dz = c[2] - s->world_max[2];
+    *rad = inside ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f;
+}
+static const float kPiF = 3.14159265358979323846f;
+static float light_power_y(const pvol_scene *s, const pvol_light &l, float worldRadius) {
+    float p[30];
+    for (int i = 0; i < 30; ++i) {
+        float I = l.intensity.c[i];
+        if (l.kind == PVOL_LIGHT_SPOT) p[i] = I * 2.f * kPiF * (1.f - .5f * (l.cos_falloff_start + l.cos_total_width));   // spot.cpp:72-75
+        else if (l.kind == PVOL_LIGHT_POINT) p[i] = I * (4.f * kPiF);                                                      // point.cpp:60-62
+        else p[i] = I * kPiF * worldRadius * worldRadius;                                                                  // distant.cpp:58-63
+    }
+    return host_spec_y(s, p);
+}
+
+static int fill_shoot_scene(pvol_ctx *c, const pvol_scene *s) {
+    DevShootScene &H = c->hsh;
+    memset(&H, 0, sizeof(H));
+    if (s->n_materials > PVOL_MAX_MATERIALS) return PVOL_E_UNSUPPORTED;
+    if (s->n_materials && !s->materials) return PVOL_E_INVALID;
+    H.nMats = (int)s->n_materials;
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const pvol_material &m = s->materials[i];
+        if (m.kind != PVOL_MATERIAL_MATTE && m.kind != PVOL_MATERIAL_GLASS) return PVOL_E_UNSUPPORTED;
+        DevMaterial &d = H.mats[i];
+        d.kind = m.kind; d.ior = m.ior; d.vn = m.vn; d.nBxdf = 0;
+        bool kdBlack = true, krBlack = true, ktBlack = true;
+        for (int b = 0; b < 30; ++b) {
+            d.kd[b] = m.kd.c[b]; d.kr[b] = m.kr.c[b]; d.kt[b] = m.kt.c[b];
+            kdBlack = kdBlack && m.kd.c[b] == 0.f; krBlack = krBlack && m.kr.c[b] == 0.f; ktBlack = ktBlack && m.kt.c[b] == 0.f;
+        }
+        if (m.kind == PVOL_MATERIAL_MATTE) { if (!kdBlack) d.bxdfType[d.nBxdf++] = 1 | 4; }          // Lambertian
+        else { if (!krBlack) d.bxdfType[d.nBxdf++] = 1 | 16; if (!ktBlack) d.bxdfType[d.nBxdf++] = 2 | 16; }
+    }
+    for (uint32_t i = 0; i < s->n_triangles; ++i) {
+        int mi = s->triangles[i].material;
+        if (mi < 0 || (uint32_t)mi >= std::max(1u, s->n_materials)) return PVOL_E_INVALID;
+        H.triMat[i] = mi;
+        H.triFlip[i] = s->triangles[i].flip_normal;
+    }
+    world_sphere(s, H.worldCenter, &H.worldRadius);
+    int n = (int)s->n_lights;
+    for (int i = 0; i < n; ++i) {
+        memcpy(H.l2w[i], s->lights[i].light_to_world, sizeof(float) * 12);
+        H.lightFunc[i] = light_power_y(s, s->lights[i], H.worldRadius);
+    }
+    if (n > 0) {
+        H.lightCdf[0] = 0.f;
+        for (int i = 1; i < n + 1; ++i) H.lightCdf[i] = H.lightCdf[i - 1] + H.lightFunc[i - 1] / n;
+        H.lightFuncInt = H.lightCdf[n];
+        if (H.lightFuncInt == 0.f) { for (int i = 1; i < n + 1; ++i) H.lightCdf[i] = float(i) / float(n); }
+        else { for (int i = 1; i < n + 1; ++i) H.lightCdf[i] /= H.lightFuncInt; }
+    }
+    H.shooterStep = c->params.shooter_step_size;
+    H.maxPhotonDepth = c->params.max_photon_depth;
+    H.finalGather = c->params.final_gather;
+    H.nCausticWanted = c->params.n_caustic_photons;
+    H.nIndirectWanted = c->params.n_indirect_photons;
+    H.nVolumeWanted = c->params.n_volume_photons;
+    return ok(hipMemcpy(c->dsh, &H, sizeof(H), hipMemcpyHostToDevice)) ? PVOL_OK : PVOL_E_NO_DEVICE;
 }
 
 static void pad32(float *dst, const pvol_spectrum &s) {
@@ -180,7 +206,7 @@ static void pad32(float *dst, const pvol_spectrum &s) {
     dst[30] = dst[31] = 0.f;
 }
 
-static int push_scene(pvol_ctx *c) {
+int pvol_push_scene(pvol_ctx *c) {
     return ok(hipMemcpy(c->ds, &c->hs, sizeof(DevScene), hipMemcpyHostToDevice)) ? PVOL_OK : PVOL_E_NO_DEVICE;
 }
 
@@ -248,8 +274,12 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         if (steps > 12000) return PVOL_E_LIMIT;
         h.maxSteps = ((int)steps + 63) & ~63;
     }
+    {
+        int rc = fill_shoot_scene(c, s);
+        if (rc != PVOL_OK) return rc;
+    }
     c->haveScene = true;
-    return push_scene(c);
+    return pvol_push_scene(c);
 }
 
 static void choose_grid(pvol_ctx *c, const float *p, uint32_t n) {
@@ -281,44 +311,44 @@ static void choose_grid(pvol_ctx *c, const float *p, uint32_t n) {
     if (h.ringMax < 1) h.ringMax = 1;
 }
 
-int pvol_upload_photons(pvol_ctx *c, const float *p, const float *wi, const float *alpha, uint32_t n) {
-    if (!c) return PVOL_E_INVALID;
-    if (!c->haveScene) return PVOL_E_NO_SCENE;
-    if (n && (!p || !wi || !alpha)) return PVOL_E_INVALID;
-    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
-    hipDeviceSynchronize();
-    free_photons(c);
+int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions) {
     DevScene &h = c->hs;
-    h.nPhotons = 0; h.cellStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
-    if (n == 0) return push_scene(c);
-    choose_grid(c, p, n);
+    choose_grid(c, hostPositions, n);
     size_t ncells = (size_t)h.gdim[0] * h.gdim[1] * h.gdim[2];
-    bool good = ok(hipMalloc(&c->dRawP, sizeof(float) * 3 * (size_t)n)) && ok(hipMalloc(&c->dRawWi, sizeof(float) * 3 * (size_t)n)) &&
-                ok(hipMalloc(&c->dRawAlpha, sizeof(float) * 30 * (size_t)n)) && ok(hipMalloc(&c->dPos4, sizeof(float4) * (size_t)n)) &&
-                ok(hipMalloc(&c->dAlpha4, sizeof(float4) * 8 * (size_t)n)) && ok(hipMalloc(&c->dWi4, sizeof(float4) * (size_t)n)) &&
-                ok(hipMalloc(&c->dCellStart, sizeof(uint32_t) * (ncells + 1)));
-    if (!good) { free_photons(c); push_scene(c); return PVOL_E_NO_MEMORY; }
-    good = ok(hipMemcpy(c->dRawP, p, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice)) &&
-           ok(hipMemcpy(c->dRawWi, wi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice)) &&
-           ok(hipMemcpy(c->dRawAlpha, alpha, sizeof(float) * 30 * (size_t)n, hipMemcpyHostToDevice));
+    bool good = ok(hipMalloc(&c->dPos4, sizeof(float4) * (size_t)n)) && ok(hipMalloc(&c->dAlpha4, sizeof(float4) * 8 * (size_t)n)) &&
+                ok(hipMalloc(&c->dWi4, sizeof(float4) * (size_t)n)) && ok(hipMalloc(&c->dCellStart, sizeof(uint32_t) * (ncells + 1)));
+    if (!good) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_MEMORY; }
     GridBuildArgs g;
     g.p = c->dRawP; g.wi = c->dRawWi; g.alpha = c->dRawAlpha; g.n = n;
     for (int a = 0; a < 3; ++a) { g.lo[a] = h.gridLo[a]; g.gdim[a] = h.gdim[a]; g.extLo[a] = h.extLo[a]; g.extHi[a] = h.extHi[a]; }
     g.inv = h.invCell;
     g.volKind = h.volKind;
     memcpy(g.w2v, h.w2v, sizeof(g.w2v));
-    good = good && ok(pvol_build_grid(&g, c->dPos4, c->dAlpha4, c->dWi4, c->dCellStart, 0));
-    if (!good) { free_photons(c); push_scene(c); return PVOL_E_NO_DEVICE; }
+    good = ok(pvol_build_grid(&g, c->dPos4, c->dAlpha4, c->dWi4, c->dCellStart, 0));
+    if (!good) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
     c->nPhotons = n;
     h.nPhotons = n; h.cellStart = c->dCellStart; h.pos4 = c->dPos4; h.alpha4 = c->dAlpha4; h.wi4 = c->dWi4;
-    return push_scene(c);
+    return pvol_push_scene(c);
 }
 
-int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
-    (void)n_tasks;
+int pvol_upload_photons(pvol_ctx *c, const float *p, const float *wi, const float *alpha, uint32_t n) {
     if (!c) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
-    return PVOL_E_UNSUPPORTED;  // device photon shooter: see pvol_shoot.hip (not built yet)
+    if (n && (!p || !wi || !alpha)) return PVOL_E_INVALID;
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    hipDeviceSynchronize();
+    pvol_free_photons(c);
+    DevScene &h = c->hs;
+    h.nPhotons = 0; h.cellStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
+    if (n == 0) return pvol_push_scene(c);
+    bool good = ok(hipMalloc(&c->dRawP, sizeof(float) * 3 * (size_t)n)) && ok(hipMalloc(&c->dRawWi, sizeof(float) * 3 * (size_t)n)) &&
+                ok(hipMalloc(&c->dRawAlpha, sizeof(float) * 30 * (size_t)n));
+    if (!good) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_MEMORY; }
+    good = ok(hipMemcpy(c->dRawP, p, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice)) &&
+           ok(hipMemcpy(c->dRawWi, wi, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice)) &&
+           ok(hipMemcpy(c->dRawAlpha, alpha, sizeof(float) * 30 * (size_t)n, hipMemcpyHostToDevice));
+    if (!good) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
+    return pvol_finish_map(c, n, p);
 }
 
 int pvol_photon_count(pvol_ctx *c, uint32_t *n) {

@@ -68,6 +68,29 @@ struct DevScene {
     int32_t maxSteps;         // upper bound of march steps per ray (lightNum array length)
 };
 
+// What only the photon shooter reads (core/photonshooter.cpp): surface materials, emission frames,
+// the light-power CDF and the shooter's own parameters.
+#define PVOL_MAX_MATERIALS 8
+struct DevMaterial {
+    int32_t kind;
+    float ior, vn;
+    int32_t nBxdf;        // components in BSDF::Add order (matte.cpp:55-60, glass.cpp:52-57)
+    int32_t bxdfType[2];  // BxDFType bits (core/reflection.h:107-121)
+    float kd[30], kr[30], kt[30];
+};
+struct DevShootScene {
+    int32_t triMat[PVOL_MAX_TRIS];
+    int32_t triFlip[PVOL_MAX_TRIS];
+    int32_t nMats;
+    DevMaterial mats[PVOL_MAX_MATERIALS];
+    float l2w[PVOL_MAX_LIGHTS][12];     // rows 0..2 of LightToWorld (spot emission, spot.cpp:106-114)
+    float worldCenter[3], worldRadius;  // BoundingSphere of Scene::WorldBound() (distant.cpp:86-100)
+    float lightFunc[PVOL_MAX_LIGHTS], lightCdf[PVOL_MAX_LIGHTS + 1], lightFuncInt;  // Distribution1D (montecarlo.h:54-76)
+    float shooterStep;
+    int32_t maxPhotonDepth, finalGather;
+    uint32_t nCausticWanted, nIndirectWanted, nVolumeWanted;
+};
+
 struct DevCounters {
     unsigned long long nRays, nSteps, nTested, nKept, nLookupsLt10, nShadowUnoccluded, nErrors, pad;
     unsigned long long cySearch, cySelect, cyFlux, cyTotal;  // s_memtime cycles summed over waves (stats build only)

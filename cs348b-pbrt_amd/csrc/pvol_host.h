@@ -1,0 +1,77 @@
+// pvol_host.h -- host-side internals shared by pvol_api.hip and pvol_shoot_host.hip
+#ifndef PVOL_HOST_H
+#define PVOL_HOST_H
+#include <hip/hip_runtime.h>
+#include <mutex>
+#include <vector>
+#include "pvol_dev.h"
+
+// ---- kernels' host entry points (pvol_march.hip, pvol_grid.hip)
+struct LiArgs {
+    const DevScene *scene;
+    const pvol_ray *rays;
+    pvol_stream *streams;
+    uint32_t nStreams;
+    uint32_t nRays;
+    int outputKind;
+    float *out;
+    uint32_t *draws;
+    const uint32_t *initState;
+    uint32_t *finalState;
+    DevCounters *counters;
+    int transmittanceOnly;
+    uint32_t *chunkCounter;
+    uint32_t *needSeq;
+    int gated;
+};
+struct GridBuildArgs {
+    const float *p, *wi, *alpha;
+    uint32_t n;
+    float lo[3];
+    float inv;
+    int32_t gdim[3];
+    int32_t volKind;
+    float extLo[3], extHi[3];
+    float w2v[16];
+};
+extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
+extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
+extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
+                                      uint32_t *cellStart, hipStream_t stream);
+
+struct pvol_ctx {
+    pvol_params params;
+    bool haveScene;
+    DevScene hs;         // host copy
+    DevScene *ds;        // device copy
+    float *dDensity;
+    // photon map
+    uint32_t nPhotons;
+    float *dRawP, *dRawWi, *dRawAlpha;  // upload order (kept for pvol_download_photons)
+    float4 *dPos4, *dAlpha4, *dWi4;
+    uint32_t *dCellStart;
+    DevCounters *dCounters;
+    uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
+    int nCU;
+    bool forceSeq;      // PVOL_FORCE_SEQ=1: always take the stream-sequential kernel (testing)
+    bool statsOn;
+    // kernel timing (HIP events on the launch stream)
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t> > pool;
+    double timeMs;
+    uint64_t launches;
+    std::mutex mu;
+    // photon shooter
+    DevShootScene hsh;
+    DevShootScene *dsh;
+    uint64_t shootStats[12];
+};
+
+
+extern "C" {
+// finish a photon map whose raw arrays (dRawP/dRawWi/dRawAlpha, n photons) are already on the device
+int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions);
+void pvol_free_photons(pvol_ctx *c);
+int pvol_push_scene(pvol_ctx *c);
+}
+#endif

@@ -56,6 +56,7 @@ def lib():
         L.pvol_get_stats.argtypes = [C.c_void_p, C.POINTER(abi.Stats), C.c_int]
         L.pvol_enable_stats.argtypes = [C.c_void_p, C.c_int]
         L.pvol_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
+        L.pvol_get_shoot_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -63,7 +64,10 @@ def lib():
 EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_default_params", "pvol_create",
            "pvol_destroy", "pvol_set_scene", "pvol_upload_photons", "pvol_preprocess", "pvol_photon_count",
            "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
-           "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms"]
+           "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats"]
+
+SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
+                    "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
 
 
 def _check(rc, where):
@@ -109,6 +113,11 @@ class PhotonVolume:
 
     def preprocess(self, n_tasks=1):
         _check(lib().pvol_preprocess(self._h, n_tasks), "pvol_preprocess")
+
+    def shoot_stats(self):
+        v = (C.c_uint64 * 12)()
+        _check(lib().pvol_get_shoot_stats(self._h, v), "pvol_get_shoot_stats")
+        return dict(zip(SHOOT_STAT_NAMES, [int(x) for x in v]))
 
     def photon_count(self):
         n = C.c_uint32()

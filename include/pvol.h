@@ -214,6 +214,12 @@ int pvol_upload_photons(pvol_ctx *ctx, const float *p, const float *wi,
  * round (photonshooter.cpp:280-351) and builds the search structure. */
 int pvol_preprocess(pvol_ctx *ctx, uint32_t n_tasks);
 
+/* Work counters of the last pvol_preprocess (the figures SURVEY 6 reports for the reference shooter):
+ * out[12] = paths, followPhoton calls, calls ending without a surface hit, transmittance-march steps,
+ * volume interactions, absorbed, stored volume / caustic / direct / indirect photons, spectral-split
+ * children, nshot. */
+int pvol_get_shoot_stats(pvol_ctx *ctx, uint64_t *out12);
+
 /* Number of photons in the current volume map. */
 int pvol_photon_count(pvol_ctx *ctx, uint32_t *n);
 /* Copies the current map back (same layout as pvol_upload_photons); capacity in photons. */

@@ -171,7 +171,7 @@ def cpu_baseline(scene, params, photons, xres, yres, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--xres", type=int, default=1280)
     ap.add_argument("--yres", type=int, default=720)
@@ -180,6 +180,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stats", action="store_true", help="collect gather work counters (slower)")
     ap.add_argument("--cell-scale", type=float, default=0.0, help="photon-grid cell edge multiplier (0 = library default)")
+    ap.add_argument("--photon-source", choices=["shoot", "synth"], default="shoot",
+                    help="shoot: device photon shooter (pvol_preprocess); synth: resampled committed map")
+    ap.add_argument("--shoot-tasks", type=int, default=16384, help="virtual PhotonShootingTasks of the device shooter")
+    ap.add_argument("--strong", action="store_true",
+                    help="N>1: partition ONE frame's tiles over the ranks (strong scaling) instead of one frame per rank")
     args = ap.parse_args()
 
     import torch
@@ -198,14 +203,26 @@ def main():
     abi, blob = pkg.abi, pkg.blob
     scene = blob.load(os.path.join(GOLD, "scene_volumescene_h.bin"))
     params = abi.params_from_blob(scene, n_volume_photons=args.photons, device=local_rank, grid_cell_scale=args.cell_scale)
-    photons = synth_photons(args.photons)
-
     pv = pvol.PhotonVolume(params)
     pv.set_scene(abi.SceneHolder(scene))
-    pv.upload_photons(*photons)
+    t_map = time.perf_counter()
+    if args.photon_source == "shoot":
+        # PhotonShooter::Preprocess on the device; every rank shoots the same map (same seeds): replicated, no traffic
+        pv.preprocess(args.shoot_tasks)
+        photons = pv.download_photons() if (rank == 0 and not args.no_cpu_baseline) else None
+        photon_note = "device shooter, %d virtual tasks" % args.shoot_tasks
+    else:
+        photons = synth_photons(args.photons)
+        pv.upload_photons(*photons)
+        photon_note = "synthetic: committed 6k-photon map of the scene resampled"
+    n_photons = pv.photon_count()
+    t_map = time.perf_counter() - t_map
 
     x0s, x1s, y0s, y1s, n_tiles = frame_tiles(args.xres, args.yres)
-    mine = np.arange(rank, n_tiles, world)          # round-robin keeps every rank's tiles spread over the frame
+    if args.strong:
+        mine = np.arange(rank, n_tiles, world)      # round-robin keeps every rank's tiles spread over the frame
+    else:
+        mine = np.arange(n_tiles)                   # weak scaling: every rank renders a whole frame of its own
     tiles = (x0s[mine], x1s[mine], y0s[mine], y1s[mine])
     rays, counts = build_rays(torch, dev, scene, args.xres, args.yres, args.spp, tiles, seed=1234 + rank)
     n_rays = int(counts.sum())
@@ -254,14 +271,15 @@ def main():
         res = {
             "metric": "volumetric photon-gather throughput (camera samples through PhotonVolumeIntegrator::Li per second)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "volumescene (homogeneous) %dx%d, %d spp, %d volume photons, nused %d, maxdist %.2f, stepsize %.2f; "
                                    "%d render tiles (MT19937 streams), %d Li() calls per step incl. filter apron" %
-                                   (args.xres, args.yres, args.spp, args.photons, params.n_used, params.max_dist, params.step_size,
+                                   (args.xres, args.yres, args.spp, n_photons, params.n_used, params.max_dist, params.step_size,
                                     n_tiles, total_rays),
-                       "photon_map": "synthetic: 6k-photon oracle-shot map of the same scene resampled to %d" % args.photons,
-                       "partition": "tiles round-robin over %d rank(s), photon map replicated, no data-path collective" % world},
+                       "photon_map": "%s: %d photons (>= %d requested), built in %.1f s (untimed setup)" % (photon_note, n_photons, args.photons, t_map),
+                       "partition": ("one frame, tiles round-robin over %d rank(s)" if args.strong else "one whole frame per rank x %d rank(s)") % world
+                                    + ", photon map replicated, no data-path collective"},
             "wall_s": dt, "checksum_xyz": checksum,
         }
         # roofline of the dominant kernel (li_kernel): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
@@ -276,9 +294,17 @@ def main():
         b_lookup = 20.0 * V + 132.0 * K
         bytes_per_launch = b_lookup * steps_per_ray * n_rays + 16.0 * n_rays + 48.0 * n_rays
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # HBM bytes of the same kernel from rocprofv3 PMC passes of tools/pvol_prof on this workload (profiles/),
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, scaled from bytes per Li() call
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj["hbm_bytes_per_ray"] * n_rays
+            traffic_src = tj["source"]
         res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                           "traffic": None,
-                           "kernel": "li_kernel", "kernel_avg_ms": kms, "kernel_launches": launches,
+                           "traffic": traffic, "traffic_source": traffic_src,
+                           "kernel": "li_par_kernel", "kernel_avg_ms": kms, "kernel_launches": launches,
                            "algorithmic_bytes_per_lookup": b_lookup, "V": V, "K": K, "lookups_per_sample": steps_per_ray,
                            "note": "B_lookup = 20*V + 132*K with V, K from the reference-algorithm counters of the CPU baseline on the same inputs"}
         if stats:

@@ -1,0 +1,124 @@
+"""N > 1 path on CPU: world_size-2 gloo processes partition the frame's render tiles exactly like
+bench.py --strong (round-robin) and bench.py default (one frame per rank), run the per-tile march with the
+ORACLE standing in for the device (there is no GPU here), and the union of the ranks' results must equal
+the single-process result.  Covers the stream bookkeeping the multi-GPU run relies on: tile -> seed,
+first_ray/n_rays partition, end_draw, and the max-over-ranks timing reduction."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, abi, load_photons, load_scene
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _tile_rays(tiles, spp, seed):
+    scene = load_scene("volumescene_h")
+    x0s, x1s, y0s, y1s = tiles
+    rays, counts = bench.build_rays(torch, torch.device("cpu"), scene, 64, 36, spp, (x0s, x1s, y0s, y1s), seed=seed)
+    r = np.zeros(len(rays), abi.RAY_DTYPE)
+    rn = rays.numpy()
+    r["o"], r["mint"], r["d"], r["maxt"], r["time"], r["scatter_u"] = rn[:, 0:3], rn[:, 3], rn[:, 4:7], rn[:, 7], rn[:, 8], rn[:, 9]
+    return r, counts
+
+
+def _march(rank_tiles, seeds, spp):
+    import orc
+    scene = load_scene("volumescene_h")
+    o = orc.Oracle(abi.SceneHolder(scene), abi.params_from_blob(scene))
+    o.set_photons(*load_photons("vh"))
+    out = {}
+    for t, seed in zip(rank_tiles, seeds):
+        x0s, x1s, y0s, y1s, _ = bench.frame_tiles(64, 36)
+        r, counts = _tile_rays((x0s[[t]], x1s[[t]], y0s[[t]], y1s[[t]]), spp, seed=1000 + int(t))
+        st = abi.make_streams(np.array([seed], np.uint32), counts.astype(np.uint32))
+        res, draws = o.li_batch(r, st, abi.OUT_XYZ)
+        out[int(t)] = (res.sum(0), int(st["end_draw"][0]))
+    return out
+
+
+def _worker(rank, world, port, strong, q):
+    try:
+        _worker_body(rank, world, port, strong, q)
+    except Exception as e:   # surface the failure instead of letting the parent wait for the queue
+        q.put((rank, "ERROR: %r" % (e,), 0.0, 0.0))
+        raise
+
+
+def _worker_body(rank, world, port, strong, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    x0s, x1s, y0s, y1s, n_tiles = bench.frame_tiles(64, 36)
+    mine = np.arange(rank, n_tiles, world) if strong else np.arange(n_tiles)
+    mine = mine[:6]   # keep the CPU suite short
+    res = _march(mine, mine, spp=2)
+    # the reductions bench.py performs: max-over-ranks time and total samples
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n = torch.tensor([float(len(mine))], dtype=torch.float64)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM)
+    dist.barrier()
+    q.put((rank, {k: (v[0].tolist(), v[1]) for k, v in res.items()}, float(t.item()), float(n.item())))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("strong", [True, False])
+def test_two_rank_tile_partition_matches_single_process(orc, strong):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, strong, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    assert not any(isinstance(g[1], str) for g in got), got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort()
+    x0s, x1s, y0s, y1s, n_tiles = bench.frame_tiles(64, 36)
+    assert n_tiles == 32   # RoundUpPow2(max(32*cores, nPixels/256)), samplerrenderer.cpp:206-208
+    for rank, res, tmax, ntot in got:
+        assert tmax == 1.5                       # max over ranks
+        mine = (np.arange(rank, n_tiles, world) if strong else np.arange(n_tiles))[:6]
+        assert ntot == 12
+        single = _march(mine, mine, spp=2)
+        for t in mine:
+            a, b = res[int(t)], single[int(t)]
+            np.testing.assert_array_equal(np.array(a[0], np.float32), b[0].astype(np.float32))
+            assert a[1] == b[1]
+    if strong:   # the two ranks cover disjoint tiles; weak: each rank renders the same whole frame's tiles
+        assert set(got[0][1]).isdisjoint(set(got[1][1]))
+    else:
+        assert set(got[0][1]) == set(got[1][1])
+
+
+def test_tiles_cover_the_sample_extent_once():
+    """Sampler::ComputeSubWindow (core/sampler.cpp:55-74) tiles partition the extent incl. the filter apron."""
+    for xres, yres in [(64, 36), (256, 256), (1280, 720)]:
+        x0s, x1s, y0s, y1s, n = bench.frame_tiles(xres, yres)
+        area = ((x1s - x0s) * (y1s - y0s)).sum()
+        assert area == (xres + 4) * (yres + 4)
+        cover = np.zeros((yres + 4, xres + 4), np.int32)
+        for a, b, c, d in zip(x0s, x1s, y0s, y1s):
+            cover[c + 2:d + 2, a + 2:b + 2] += 1
+        assert (cover == 1).all()
+    assert bench.frame_tiles(1280, 720)[4] == 4096

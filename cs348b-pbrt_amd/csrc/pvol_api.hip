@@ -118,6 +118,8 @@ void pvol_destroy(pvol_ctx *c) {
     for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->dDensity) hipFree(c->dDensity);
+    if (c->dRecords) hipFree(c->dRecords);
+    if (c->dState) hipFree(c->dState);
     if (c->ds) hipFree(c->ds);
     if (c->dsh) hipFree(c->dsh);
     if (c->dCounters) hipFree(c->dCounters);
@@ -260,7 +262,7 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     h.candCap = ((c->params.n_used + 63) / 64) * 64 + 192;
     // march-step bound: diagonal of the volume's world bound / stepSize (rays are clipped to the extent)
     h.maxSteps = 0;
-    if (s->n_lights > 1 && v.kind != PVOL_VOLUME_NONE) {
+    if ((s->n_lights > 1 || v.kind == PVOL_VOLUME_GRID) && v.kind != PVOL_VOLUME_NONE) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < 8; ++k) {
             float x = (k & 1) ? v.extent_max[0] : v.extent_min[0], y = (k & 2) ? v.extent_max[1] : v.extent_min[1],
@@ -377,8 +379,10 @@ static size_t lds_bytes_par(const pvol_ctx *c) { return (size_t)c->hs.candCap * 
 static bool par_eligible(const pvol_ctx *c) { return c->hs.nLights <= 1 && c->hs.volKind != PVOL_VOLUME_GRID; }
 
 static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
-                  float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, hipStream_t stream) {
+                  float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, uint32_t maxRaysPerStream,
+                  hipStream_t stream) {
     LiArgs a;
+    memset(&a, 0, sizeof(a));
     a.scene = c->ds; a.rays = dRays; a.streams = dStreams; a.nStreams = nStreams; a.nRays = nRays; a.outputKind = outputKind;
     a.out = dOut; a.draws = dDraws; a.initState = dInit; a.finalState = dFinal; a.counters = c->dCounters;
     a.transmittanceOnly = transOnly;
@@ -391,6 +395,33 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
     }
     hipError_t e;
     const bool par = par_eligible(c) && !dInit && !c->forceSeq;
+    // scenes where drawn values matter: sequential RESOLVE pre-pass + ray-parallel REPLAY, slice by slice
+    const bool sliced = !par && !c->forceSeq && !transOnly && c->hs.volKind != PVOL_VOLUME_NONE;
+    uint32_t sliceM = 0, nSlices = 0;
+    if (sliced) {
+        uint32_t maxRays = maxRaysPerStream;
+        if (maxRays == 0) {   // device entry point: the stream table lives on the device
+            std::vector<pvol_stream> hs(nStreams);
+            if (!ok(hipMemcpy(hs.data(), dStreams, sizeof(pvol_stream) * (size_t)nStreams, hipMemcpyDeviceToHost))) return PVOL_E_NO_DEVICE;
+            for (uint32_t i = 0; i < nStreams; ++i) maxRays = std::max(maxRays, hs[i].n_rays);
+        }
+        const bool grid = c->hs.volKind == PVOL_VOLUME_GRID;
+        size_t stride = 16 + (size_t)((c->hs.maxSteps + 15) & ~15) + (grid ? 8 * (size_t)c->hs.maxSteps : 0);
+        stride = (stride + 15) & ~(size_t)15;
+        const size_t budget = (size_t)2 << 30;
+        size_t m = budget / (stride * (size_t)nStreams);
+        m = std::max<size_t>(64, std::min<size_t>(m, ((size_t)maxRays + 63) & ~(size_t)63));
+        m &= ~(size_t)63;
+        if (const char *ev = getenv("PVOL_SLICE_RAYS")) { long v = atol(ev); if (v >= 64) m = (size_t)v & ~(size_t)63; }   // testing: force many slices
+        sliceM = (uint32_t)m;
+        nSlices = maxRays ? (maxRays + sliceM - 1) / sliceM : 1;
+        size_t recBytes = stride * (size_t)nStreams * sliceM, stBytes = sizeof(uint32_t) * 625 * (size_t)nStreams;
+        if (recBytes > c->recBytes) { if (c->dRecords) hipFree(c->dRecords); c->dRecords = 0; c->recBytes = 0;
+                                      if (!ok(hipMalloc(&c->dRecords, recBytes))) return PVOL_E_NO_MEMORY; c->recBytes = recBytes; }
+        if (stBytes > c->stateBytes) { if (c->dState) hipFree(c->dState); c->dState = 0; c->stateBytes = 0;
+                                       if (!ok(hipMalloc(&c->dState, stBytes))) return PVOL_E_NO_MEMORY; c->stateBytes = stBytes; }
+        a.records = c->dRecords; a.recStride = (uint32_t)stride; a.sliceM = sliceM; a.state = c->dState;
+    }
     if (par) hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
     hipEventRecord(ev.first, stream);
     if (par) {
@@ -400,6 +431,15 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
         if (ok(e)) {   // runs only if a ray raised needSeq (gate read on the device: no host sync here)
             a.gated = 1;
             e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
+        }
+    } else if (sliced) {
+        e = hipSuccess;
+        unsigned long long chunks = (unsigned long long)((sliceM + 63) / 64) * nStreams;
+        uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
+        for (uint32_t k = 0; k < nSlices && ok(e); ++k) {
+            a.sliceK = k;
+            hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
+            e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
         }
     } else {
         e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
@@ -418,7 +458,7 @@ int pvol_li_batch_device(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvo
     if (outputKind != PVOL_OUT_SPECTRAL && outputKind != PVOL_OUT_XYZ) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
     if (!nStreams) return PVOL_OK;
-    return launch(c, dRays, nRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, (hipStream_t)hipStream);
+    return launch(c, dRays, nRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, 0, (hipStream_t)hipStream);
 }
 
 static int check_errors(pvol_ctx *c) {
@@ -437,11 +477,13 @@ static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_st
     if (!c || (nRays && (!rays || !out)) || (nStreams && !streams)) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    uint32_t maxRays = 1;
     {   // streams must partition the ray array in order (every ray belongs to exactly one stream)
         uint64_t next = 0;
         for (uint32_t s = 0; s < nStreams; ++s) {
             if (streams[s].first_ray != next) return PVOL_E_INVALID;
             next += streams[s].n_rays;
+            maxRays = std::max(maxRays, streams[s].n_rays);
         }
         if (next != nRays) return PVOL_E_INVALID;
     }
@@ -460,7 +502,7 @@ static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_st
         if (good && mtState) good = ok(hipMemcpy(dState, mtState, sizeof(uint32_t) * 625 * (size_t)nStreams, hipMemcpyHostToDevice));
         if (!good) rc = PVOL_E_NO_DEVICE;
     }
-    if (rc == PVOL_OK) rc = launch(c, dRays, nRays, dStreams, nStreams, transOnly ? PVOL_OUT_SPECTRAL : outputKind, dOut, dDraws, dState, dState, transOnly, 0);
+    if (rc == PVOL_OK) rc = launch(c, dRays, nRays, dStreams, nStreams, transOnly ? PVOL_OUT_SPECTRAL : outputKind, dOut, dDraws, dState, dState, transOnly, maxRays, 0);
     if (rc == PVOL_OK && !ok(hipDeviceSynchronize())) rc = PVOL_E_NO_DEVICE;
     if (rc == PVOL_OK) rc = check_errors(c);
     if (rc == PVOL_OK) {

@@ -23,6 +23,9 @@ struct LiArgs {
     uint32_t *chunkCounter;
     uint32_t *needSeq;
     int gated;
+    unsigned char *records;
+    uint32_t recStride, sliceM, sliceK;
+    uint32_t *state;
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
@@ -35,6 +38,8 @@ struct GridBuildArgs {
     float w2v[16];
 };
 extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
+extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
+                                           uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
                                       uint32_t *cellStart, hipStream_t stream);
@@ -61,6 +66,11 @@ struct pvol_ctx {
     double timeMs;
     uint64_t launches;
     std::mutex mu;
+    // resolve/replay scratch (grown on demand)
+    unsigned char *dRecords = 0;
+    size_t recBytes = 0;
+    uint32_t *dState = 0;
+    size_t stateBytes = 0;
     // photon shooter
     DevShootScene hsh;
     DevShootScene *dsh;

@@ -372,6 +372,11 @@ struct LiArgs {
     uint32_t *chunkCounter;     // li_par_kernel: next chunk of CHUNK_RAYS rays
     uint32_t *needSeq;          // li_par_kernel sets it when a ray reaches the roulette; li_seq_kernel runs only if set (gate)
     int gated;                  // li_seq_kernel: 1 = return at once unless *needSeq
+    // resolve + replay (scenes where drawn values matter): rays are processed in slices, slice k of a stream =
+    // its rays [k*sliceM, (k+1)*sliceM); the MT state of every stream persists in `state` between slices
+    unsigned char *records;     // [nStreams * sliceM] slots of recStride bytes
+    uint32_t recStride, sliceM, sliceK;
+    uint32_t *state;            // [nStreams][625]
 };
 
 // PhotonVolumeIntegrator::Transmittance with sample == NULL (photonvolume.cpp:15-30)
@@ -439,15 +444,46 @@ struct MarchLds {
 
 // One call of PhotonVolumeIntegrator::Li (or Transmittance).  Returns false only in !SEQ mode when the ray
 // needs a drawn VALUE (Russian roulette): the caller must redo the batch sequentially.
-template <bool STATS, bool SEQ, int NREG>
+// How a march consumes the render tile's RNG stream:
+//   MODE_SEQ      draws from the MT19937 state in LDS, everything in one pass (always legal)
+//   MODE_PAR      only counts draws: legal when no drawn value can reach the result
+//   MODE_RESOLVE  draws like MODE_SEQ but only RECORDS what the values decide (light per step, roulette
+//                 outcome, tau() offsets) and skips gather and radiance: the cheap sequential pre-pass
+//   MODE_REPLAY   no RNG: reads the records, so rays are independent and run one wave each
+#define MODE_SEQ 0
+#define MODE_PAR 1
+#define MODE_RESOLVE 2
+#define MODE_REPLAY 3
+// Per-ray record slot: header {u32 nEff, u32 flags (bit0: the roulette killed the ray at step nEff), u32 draws,
+// u32 pad}, then one byte per step (bits 0-2 light, bit 7 "survived a roulette: Tr /= 0.5"), then -- VolumeGrid
+// only -- two floats per step (tau() offset of the step, offset of the shadow ray).
+struct RayRec {
+    uint32_t *hdr;
+    unsigned char *stepByte;
+    float *stepU;   // null unless VolumeGrid
+};
+__device__ __forceinline__ RayRec ray_rec(unsigned char *slot, int maxSteps, bool grid) {
+    RayRec r;
+    r.hdr = reinterpret_cast<uint32_t *>(slot);
+    r.stepByte = slot + 16;
+    r.stepU = grid ? reinterpret_cast<float *>(slot + 16 + ((maxSteps + 15) & ~15)) : 0;
+    return r;
+}
+
+// One call of PhotonVolumeIntegrator::Li (or Transmittance).  Returns false only in MODE_PAR when the ray
+// needs a drawn VALUE (Russian roulette): the caller must redo the batch sequentially.
+template <bool STATS, int MODE, int NREG>
 __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr, Rng &rng, MarchLds &M, int lane,
-                          WaveCounters &wc, f4 *LvOut, f4 *TrOut) {
+                          WaveCounters &wc, f4 *LvOut, f4 *TrOut, RayRec rec) {
+    constexpr bool RNGON = (MODE == MODE_SEQ || MODE == MODE_RESOLVE);
+    constexpr bool RADIANCE = (MODE != MODE_RESOLVE);
     const int q = lane & 7;
     const f4 sigA = ld4(S.sigA, q), sigS = ld4(S.sigS, q);
     const f4 sigT = sigA + sigS;
     const f4 Y = ld4(S.cieY, q);
     const int nLights = S.nLights;
     const bool rainbow = (S.volKind == PVOL_VOLUME_RAINBOW);
+    const bool grid = (S.volKind == PVOL_VOLUME_GRID);
     RayD ray;
     ray.o = v3(pr.o[0], pr.o[1], pr.o[2]);
     ray.d = v3(pr.d[0], pr.d[1], pr.d[2]);
@@ -456,18 +492,22 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
     f4 Lv = mk4(0.f), Tr = mk4(1.f);
     if (STATS) ++wc.rays;
     if (A.transmittanceOnly) {
-        *TrOut = transmittance<SEQ>(S, ray, rng, sigT, lane);
+        *TrOut = transmittance<RNGON>(S, ray, rng, sigT, lane);
         *LvOut = Lv;
         return true;
     }
     float t0, t1;
     bool hit = S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
     int nSamples = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
-    if (SEQ && hit && nLights > 1 && nSamples > S.maxSteps) {
-        // the LDS plan cannot hold this ray's lightNum[] array: report, never guess
+    if (MODE != MODE_PAR && hit && nSamples > S.maxSteps && (nLights > 1 || MODE >= MODE_RESOLVE)) {
+        // the LDS / record plan cannot hold this ray's per-step arrays: report, never guess
         if (lane == 0) atomicAdd(&A.counters->nErrors, 1ull);
         hit = false;
+        nSamples = 0;
     }
+    int nEff = nSamples;
+    bool killed = false;
+    if (MODE == MODE_REPLAY) { nEff = (int)rec.hdr[0]; killed = (rec.hdr[1] & 1u) != 0u; }
     if (hit) {
         float step = (t1 - t0) / nSamples;
         V3 p = ray.o + ray.d * t0, pPrev;
@@ -476,14 +516,14 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
         // LDShuffleScrambled1D(1,n,lightNum) + (1,n,lightComp) + 2D(1,n,lightPos): 4+6n draws
         // (photonvolume.cpp:137-142).  The three delta lights ignore lightComp/lightPos, and lightNum only
         // matters with more than one light: what is never read is only counted.
-        if (SEQ && nLights > 1) {
+        if (RNGON && nLights > 1) {
             float *lightNum = M.lightNum;
-            uint32_t scramble = rng_uint<SEQ>(rng, lane);
+            uint32_t scramble = rng_uint<RNGON>(rng, lane);
             for (int i = lane; i < nSamples; i += LANES) lightNum[i] = van_der_corput((uint32_t)i, scramble);
-            rng_skip<SEQ>(rng, (unsigned long long)nSamples, lane);  // n one-element shuffles (montecarlo.h:308-309)
+            rng_skip<RNGON>(rng, (unsigned long long)nSamples, lane);  // n one-element shuffles (montecarlo.h:308-309)
             __syncthreads();
-            for (int i = 0; i < nSamples; ++i) {                     // Shuffle(samples, n, 1), montecarlo.h:174-181
-                uint32_t other = (uint32_t)i + (rng_uint<SEQ>(rng, lane) % (uint32_t)(nSamples - i));
+            for (int i = 0; i < nSamples; ++i) {                       // Shuffle(samples, n, 1), montecarlo.h:174-181
+                uint32_t other = (uint32_t)i + (rng_uint<RNGON>(rng, lane) % (uint32_t)(nSamples - i));
                 if (lane == 0) {
                     float a = lightNum[i], b = lightNum[other];
                     lightNum[i] = b;
@@ -491,9 +531,9 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
                 }
             }
             __syncthreads();
-            rng_skip<SEQ>(rng, 3ull + 4ull * (unsigned long long)nSamples, lane);
+            rng_skip<RNGON>(rng, 3ull + 4ull * (unsigned long long)nSamples, lane);
         } else {
-            rng_skip<SEQ>(rng, 4ull + 6ull * (unsigned long long)nSamples, lane);
+            rng_skip<RNGON>(rng, 4ull + 6ull * (unsigned long long)nSamples, lane);
         }
         const f4 le = ld4(S.le, q);
         // step invariants where the density factor is exactly 1 (inside a homogeneous extent):
@@ -502,20 +542,24 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
         const bool blackS1 = spec_is_black(sigS);
         const f4 albedo1 = clean4(fdiv4(sigS, sigA + sigS), q);
         float lastRk = 0.f;
-        const bool analytic = (S.volKind != PVOL_VOLUME_GRID);
+        const bool analytic = !grid;
         bool inPrev = analytic && box_inside(S.extLo, S.extHi, xform_point(S.w2v, p));
         int cachedLn = -1;          // light whose direction-only shadow-ray terms are cached (distant lights)
         TriPre triPre;
         V3 cDvInv = v3(0.f, 0.f, 0.f);
         triPre.valid = false;
-        for (int i = 0; i < nSamples; ++i, t0 += step) {
+        for (int i = 0; i < nEff; ++i, t0 += step) {
             if (STATS) ++wc.steps;
             pPrev = p;
             p = ray.o + ray.d * t0;
             const V3 pv = xform_point(S.w2v, p);
             const bool inP = analytic && box_inside(S.extLo, S.extHi, pv);
+            unsigned int recByte = 0u;
+            if (MODE == MODE_REPLAY) recByte = rec.stepByte[i];
             f4 stepTau;
-            const float uTau = rng_float<SEQ>(rng, lane);
+            float uTau = rng_float<RNGON>(rng, lane);
+            if (MODE == MODE_REPLAY && grid) uTau = rec.stepU[2 * i];
+            if (MODE == MODE_RESOLVE && grid && lane == 0) rec.stepU[2 * i] = uTau;
             if (inPrev && inP) {
                 // both ends inside the extent: the slab clip of the [0,1] segment is the identity
                 // (homogeneous.h:80-84 -> Distance(ray(0), ray(1)) * sigma_t)
@@ -529,11 +573,18 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
             }
             inPrev = inP;
             Tr = exp4(neg4(stepTau));   // assigned, not accumulated (photonvolume.cpp:155)
-            if (spec_y(Tr, Y) < 1e-3) {
-                if (!SEQ) return false;  // the roulette compares a drawn value: sequential path only
+            if (MODE == MODE_REPLAY) {
+                if (recByte & 0x80u) Tr = Tr / .5f;
+            } else if (spec_y(Tr, Y) < 1e-3) {
+                if (MODE == MODE_PAR) return false;  // the roulette compares a drawn value
                 const float continueProb = .5f;
-                if (rng_float<SEQ>(rng, lane) > continueProb) { Tr = mk4(0.f); break; }
+                if (rng_float<RNGON>(rng, lane) > continueProb) {
+                    Tr = mk4(0.f);
+                    if (MODE == MODE_RESOLVE) { nEff = i; killed = true; }
+                    break;
+                }
                 Tr = Tr / continueProb;
+                recByte |= 0x80u;
             }
             const float dens = analytic ? (inP ? 1.f : 0.f) : grid_density(S, pv);   // homogeneous.h:64-75 / volume.h:81-92
             f4 ss = sigS * dens, sa = sigA * dens;
@@ -541,7 +592,9 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
             const bool unit = (dens == 1.f);
             if (!(unit ? blackS1 : spec_is_black(ss)) && nLights > 0) {
                 int ln = 0;
-                if (SEQ && nLights > 1) ln = min((int)floorf(M.lightNum[i] * nLights), nLights - 1);
+                if (RNGON && nLights > 1) ln = min((int)floorf(M.lightNum[i] * nLights), nLights - 1);
+                if (MODE == MODE_REPLAY) ln = (int)(recByte & 7u);
+                recByte |= (unsigned int)ln;
                 const DevLight &light = S.lights[ln];
                 // Light::Sample_L(p, 0, ...): distant.cpp:48-55, point.cpp:50-57, spot.cpp:50-57
                 V3 wo;
@@ -588,40 +641,50 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
                 }
                 if (lit) {
                     if (STATS) ++wc.unocc;
-                    f4 Ttr;
-                    if (inP) {   // analytic tau() from a point inside the extent (photonvolume.cpp:15-30, one draw)
-                        (void)rng_float<SEQ>(rng, lane);
-                        V3 dvInv = cDvInv;
-                        if (!(distant && S.nTris <= LANES)) {
-                            V3 dv = xform_vector(S.w2v, vis.d);
-                            dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
+                    // vis.Transmittance(..., NULL, rng, ...): one draw (photonvolume.cpp:24-27)
+                    float uSh = rng_float<RNGON>(rng, lane);
+                    if (MODE == MODE_REPLAY && grid) uSh = rec.stepU[2 * i + 1];
+                    if (MODE == MODE_RESOLVE && grid && lane == 0) rec.stepU[2 * i + 1] = uSh;
+                    if (RADIANCE) {
+                        f4 Ttr;
+                        if (inP) {   // analytic tau() from a point inside the extent
+                            V3 dvInv = cDvInv;
+                            if (!(distant && S.nTris <= LANES)) {
+                                V3 dv = xform_vector(S.w2v, vis.d);
+                                dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
+                            }
+                            Ttr = exp4(neg4(sigT * inside_exit_length(S, vis.o, vis.d, pv, dvInv, vis.maxt)));
+                        } else {
+                            Ttr = exp4(neg4(vol_tau(S, vis, 4.f * S.stepSize, uSh, sigT)));
                         }
-                        Ttr = exp4(neg4(sigT * inside_exit_length(S, vis.o, vis.d, pv, dvInv, vis.maxt)));
-                    } else {
-                        Ttr = transmittance<SEQ>(S, vis, rng, sigT, lane);
-                    }
-                    f4 Ld = L * Ttr;
-                    if (rainbow) L_d = rainbow_reflection(Ld, ray.d, wo, q);
-                    else {
-                        // vr->p(p, w, -wo): homogeneous.h:76-79 (0 outside the extent), DensityRegion::p otherwise
-                        float ph = (analytic && !inP) ? 0.f : phase_hg(w, -wo, S.g);
-                        L_d = Ld * ph * float(nLights) / pdf;
+                        f4 Ld = L * Ttr;
+                        if (rainbow) L_d = rainbow_reflection(Ld, ray.d, wo, q);
+                        else {
+                            // vr->p(p, w, -wo): homogeneous.h:76-79 (0 outside the extent), DensityRegion::p otherwise
+                            float ph = (analytic && !inP) ? 0.f : phase_hg(w, -wo, S.g);
+                            L_d = Ld * ph * float(nLights) / pdf;
+                        }
                     }
                 }
             }
-            if (!rainbow) {
-                float guess = i < PREV_N ? fmaxf(M.prevRk[i], lastRk) : lastRk;
-                float rk;
-                L_ii = lphoton<STATS, NREG>(S, M.G, w, p, ss, lane, wc, guess, &rk);
-                lastRk = rk;
-                if (i < PREV_N && lane == 0) M.prevRk[i] = rk;
+            if (MODE == MODE_RESOLVE && lane == 0) rec.stepByte[i] = (unsigned char)recByte;
+            if (RADIANCE) {
+                if (!rainbow) {
+                    float guess = i < PREV_N ? fmaxf(M.prevRk[i], lastRk) : lastRk;
+                    float rk;
+                    L_ii = lphoton<STATS, NREG>(S, M.G, w, p, ss, lane, wc, guess, &rk);
+                    lastRk = rk;
+                    if (i < PREV_N && lane == 0) M.prevRk[i] = rk;
+                }
+                const float ySa = unit ? ySa1 : spec_y(sa, Y), ySs = unit ? ySs1 : spec_y(ss, Y);
+                if (ySa != 0.0 || ySs != 0.0) L_i = L_d + (unit ? albedo1 : clean4(fdiv4(ss, sa + ss), q)) * L_ii;
+                else L_i = L_d;
+                Lv = (sa * (le * dens) * step) + (ss * L_i * step) + (Tr * Lv);
             }
-            const float ySa = unit ? ySa1 : spec_y(sa, Y), ySs = unit ? ySs1 : spec_y(ss, Y);
-            if (ySa != 0.0 || ySs != 0.0) L_i = L_d + (unit ? albedo1 : clean4(fdiv4(ss, sa + ss), q)) * L_ii;
-            else L_i = L_d;
-            Lv = (sa * (le * dens) * step) + (ss * L_i * step) + (Tr * Lv);
         }
+        if (MODE == MODE_REPLAY && killed) Tr = mk4(0.f);
     }
+    if (MODE == MODE_RESOLVE && lane == 0) { rec.hdr[0] = (uint32_t)nEff; rec.hdr[1] = killed ? 1u : 0u; }
     *LvOut = Lv;
     *TrOut = Tr;
     return true;
@@ -709,7 +772,8 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_seq_kernel(LiArgs A) {
         rng_skip<true>(rng, pr.rng_skip, lane);
         const unsigned long long d0 = rng.draws;
         f4 Lv, Tr;
-        march_ray<STATS, true, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr);
+        RayRec none = {0, 0, 0};
+        march_ray<STATS, MODE_SEQ, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, none);
         write_outputs(S, A, ri, Lv, Tr, lane);
         if (A.draws && lane == 0) A.draws[ri] = (uint32_t)(rng.draws - d0);
     }
@@ -776,7 +840,8 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
             const pvol_ray pr = A.rays[ri];
             rng.draws = 0;
             f4 Lv, Tr;
-            bool okRay = march_ray<STATS, false, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr);
+            RayRec none = {0, 0, 0};
+            bool okRay = march_ray<STATS, MODE_PAR, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, none);
             if (!okRay) {
                 if (lane == 0) atomicOr(A.needSeq, 1u);
                 continue;
@@ -786,6 +851,111 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
             acc += rng.draws + pr.rng_skip;
         }
         if (lane == 0 && acc) atomicAdd((unsigned long long *)&A.streams[sidx].end_draw, acc);
+    }
+    flush_counters<STATS>(A.counters, wc, tk0, lane);
+}
+
+// Sequential pre-pass of slice sliceK: one wave per stream draws through the slice's rays in order and records
+// what the drawn values decide.  No gather, no radiance: a few hundred instructions per march step.
+template <bool STATS, int NREG>
+__global__ __launch_bounds__(LANES, PVOL_WPE) void li_resolve_kernel(LiArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    const uint32_t sidx = blockIdx.x;
+    if (sidx >= A.nStreams) return;
+    uint32_t *mt = reinterpret_cast<uint32_t *>(lds);
+    MarchLds M;
+    M.G.cap = 0; M.G.cd = 0; M.G.ci = 0;
+    M.lightNum = reinterpret_cast<float *>(lds + MT_N * 4);
+    M.prevRk = 0;
+    pvol_stream st = A.streams[sidx];
+    const uint32_t begin = A.sliceK * A.sliceM;
+    if (begin >= st.n_rays && !(A.sliceK == 0)) return;
+    Rng rng;
+    rng.mt = mt;
+    rng.draws = 0;
+    uint32_t *state = A.state + (size_t)sidx * (MT_N + 1);
+    if (A.sliceK == 0 && !A.initState) {
+        mt_seed(mt, st.seed, lane);
+        rng.mti = MT_N;
+        rng_skip<true>(rng, st.start_draw, lane);
+    } else {
+        const uint32_t *src = (A.sliceK == 0) ? A.initState + (size_t)sidx * (MT_N + 1) : state;
+        for (int i = lane; i < MT_N; i += LANES) mt[i] = src[i];
+        rng.mti = (int)src[MT_N];
+        rng.draws = (A.sliceK == 0) ? st.start_draw : st.end_draw;
+        __syncthreads();
+    }
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    const bool grid = (S.volKind == PVOL_VOLUME_GRID);
+    const uint32_t end = min(st.n_rays, begin + A.sliceM);
+    for (uint32_t k = begin; k < end; ++k) {
+        const size_t ri = (size_t)st.first_ray + k;
+        const pvol_ray pr = A.rays[ri];
+        rng_skip<true>(rng, pr.rng_skip, lane);
+        const unsigned long long d0 = rng.draws;
+        RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k - begin)) * A.recStride, S.maxSteps, grid);
+        f4 Lv, Tr;
+        march_ray<false, MODE_RESOLVE, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
+        if (lane == 0) rec.hdr[2] = (uint32_t)(rng.draws - d0);
+        if (A.draws && lane == 0) A.draws[ri] = (uint32_t)(rng.draws - d0);
+    }
+    if (lane == 0) A.streams[sidx].end_draw = rng.draws;
+    __syncthreads();
+    for (int i = lane; i < MT_N; i += LANES) state[i] = mt[i];
+    if (lane == 0) state[MT_N] = (uint32_t)rng.mti;
+    if (A.finalState && end >= st.n_rays) {
+        uint32_t *dst = A.finalState + (size_t)sidx * (MT_N + 1);
+        for (int i = lane; i < MT_N; i += LANES) dst[i] = mt[i];
+        if (lane == 0) dst[MT_N] = (uint32_t)rng.mti;
+    }
+}
+
+// Heavy pass of slice sliceK: one wave per ray, chunk c = 64 consecutive rays of one stream's slice.
+template <bool STATS, int NREG>
+__global__ __launch_bounds__(LANES, PVOL_WPE) void li_replay_kernel(LiArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    MarchLds M;
+    M.G.cap = S.candCap;
+    M.G.cd = reinterpret_cast<float *>(lds);
+    M.G.ci = reinterpret_cast<uint32_t *>(lds + (size_t)M.G.cap * 4);
+    M.lightNum = 0;
+    M.prevRk = reinterpret_cast<float *>(lds + (size_t)M.G.cap * 8);
+    for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
+    __syncthreads();
+    Rng rng;
+    rng.mt = 0;
+    rng.mti = 0;
+    rng.draws = 0;
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long tk0 = STATS ? stamp() : 0ull;
+    const bool grid = (S.volKind == PVOL_VOLUME_GRID);
+    const uint32_t chunksPerSlice = (A.sliceM + CHUNK_RAYS - 1) / CHUNK_RAYS;
+    const unsigned long long nChunks = (unsigned long long)chunksPerSlice * A.nStreams;
+    for (;;) {
+        uint32_t chunk = 0;
+        if (lane == 0) chunk = atomicAdd(A.chunkCounter, 1u);
+        chunk = __shfl(chunk, 0);
+        if (chunk >= nChunks) break;
+        const uint32_t sidx = chunk / chunksPerSlice, j = chunk - sidx * chunksPerSlice;
+        const uint32_t nr = A.streams[sidx].n_rays, first = A.streams[sidx].first_ray;
+        const uint32_t begin = A.sliceK * A.sliceM;
+        if (begin >= nr) continue;
+        const uint32_t sliceLen = min(nr - begin, A.sliceM);
+        const uint32_t l0 = j * CHUNK_RAYS;
+        if (l0 >= sliceLen) continue;
+        const uint32_t l1 = min(sliceLen, l0 + CHUNK_RAYS);
+        for (uint32_t l = l0; l < l1; ++l) {
+            const size_t ri = (size_t)first + begin + l;
+            const pvol_ray pr = A.rays[ri];
+            RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + l) * A.recStride, S.maxSteps, grid);
+            f4 Lv, Tr;
+            march_ray<STATS, MODE_REPLAY, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
+            write_outputs(S, A, ri, Lv, Tr, lane);
+        }
     }
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
@@ -812,6 +982,22 @@ extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, in
     } else {
         if (stats) hipLaunchKernelGGL((li_par_kernel<true, 12>), grid, block, ldsBytes, stream, *args);
         else hipLaunchKernelGGL((li_par_kernel<false, 12>), grid, block, ldsBytes, stream, *args);
+    }
+    return hipGetLastError();
+}
+
+// one slice: resolve (wave per stream) then replay (wave per ray); chunkCounter must be zero before the replay
+extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
+                                           uint32_t nWaves, hipStream_t stream) {
+    dim3 block(LANES);
+    if (candCap <= 4 * LANES) {
+        hipLaunchKernelGGL((li_resolve_kernel<false, 4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+        if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 4>), dim3(nWaves), block, ldsReplay, stream, *args);
+        else hipLaunchKernelGGL((li_replay_kernel<false, 4>), dim3(nWaves), block, ldsReplay, stream, *args);
+    } else {
+        hipLaunchKernelGGL((li_resolve_kernel<false, 12>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+        if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 12>), dim3(nWaves), block, ldsReplay, stream, *args);
+        else hipLaunchKernelGGL((li_replay_kernel<false, 12>), dim3(nWaves), block, ldsReplay, stream, *args);
     }
     return hipGetLastError();
 }

@@ -175,3 +175,32 @@ def test_edge_cases(pvol):
     with pytest.raises(pvol.PvolError):
         pv.li(rays, bad)
     pv.close()
+
+
+def test_resolve_replay_across_many_slices(pvol, monkeypatch):
+    """Multi-light / VolumeGrid scenes run as a sequential RNG pre-pass + ray-parallel replay, slice by slice,
+    with every stream's MT19937 state carried between slices.  Force 64-ray slices and long streams, and
+    compare with the one-pass stream-sequential kernel."""
+    for name in ["pf_k50", "grid16"]:
+        s, p, rays, streams, c = load_li_case(name)
+        tag = LI_CASES[name][1]
+        n = len(rays)
+        rays3 = np.concatenate([rays, rays, rays])
+        # one long stream + one short one, so slices end in the middle of a stream
+        st = abi.make_streams(np.array([11, 12], np.uint32), np.array([3 * n - 7, 7], np.uint32), start_draw=np.array([5, 0], np.uint64))
+        monkeypatch.setenv("PVOL_SLICE_RAYS", "64")
+        pv = _ctx(pvol, s, p, load_photons(tag))
+        st1 = st.copy()
+        out, draws = pv.li(rays3, st1)
+        monkeypatch.setenv("PVOL_FORCE_SEQ", "1")
+        pv2 = _ctx(pvol, s, p, load_photons(tag))
+        st2 = st.copy()
+        ref, rdraws = pv2.li(rays3, st2)
+        monkeypatch.delenv("PVOL_FORCE_SEQ")
+        assert (draws == rdraws).all()
+        assert (st1["end_draw"] == st2["end_draw"]).all()
+        floor = 1e-6 * float(np.abs(ref[:, :30]).max())
+        assert rel_l2(out[:, :30], ref[:, :30], floor=floor).max() <= 1e-6
+        assert (out[:, 30:] == ref[:, 30:]).all()
+        pv.close()
+        pv2.close()

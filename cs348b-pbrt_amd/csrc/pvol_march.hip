@@ -30,7 +30,7 @@
 #define PREV_N 256   // march steps for which the previous ray's k-th distance^2 is remembered
 #define CHUNK_RAYS 64
 #ifndef PVOL_WPE
-#define PVOL_WPE 2   // minimum waves per SIMD the register allocator must leave room for
+#define PVOL_WPE 3   // minimum waves per SIMD the register allocator must leave room for (3 measured best: profiles/)
 #endif
 
 // ------------------------------------------------------------------------------------------ RNG
@@ -295,7 +295,8 @@ __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, i
     int nFound = count;
     float maxmd;
     if (count > k) {
-        maxmd = select_k<NREG>(G, count, k, T, lane);
+        // the usual case after a guessed radius: ~1.5-2 k candidates, two registers per lane are enough
+        maxmd = (count <= 2 * LANES) ? select_k<2>(G, count, k, T, lane) : select_k<NREG>(G, count, k, T, lane);
         nFound = k;
     } else {
         float m = 0.f;
@@ -690,6 +691,198 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
     return true;
 }
 
+// ---- blocked march for the two ray-parallel modes over an analytic (homogeneous / rainbow) medium.
+// Everything about a march step that is SCALAR -- sample point, inside test, segment length, light
+// geometry, shadow-ray occlusion, exit distance of the shadow ray -- is evaluated for 64 steps at once,
+// one step per lane; the serial loop that follows only does the spectral arithmetic and the gather, reading
+// each step's scalars back with wave-uniform lane reads.  Returns 0 = done, 1 = the ray needs the roulette
+// (MODE_PAR: redo sequentially), 2 = not applicable (the caller runs march_ray).
+// tau() length of a homogeneous extent along a general segment (homogeneous.h:80-84): Distance(ray(t0), ray(t1))
+__device__ __forceinline__ float analytic_tau_length(const DevScene &S, V3 o, V3 d, float mint, float maxt) {
+    RayD r;
+    r.o = o; r.d = d; r.mint = mint; r.maxt = maxt;
+    float t0, t1;
+    if (!vol_intersect(S, r, &t0, &t1)) return 0.f;
+    V3 a = o + d * t0, b = o + d * t1;
+    return len(a - b);
+}
+__device__ __forceinline__ bool lane_occluded(const DevScene &S, const RayD &vis) {
+    bool hit = false;
+    for (int t = 0; t < S.nTris && !hit; ++t) hit = tri_hit(S.tris[t], vis);
+    return hit;
+}
+
+template <bool STATS, int MODE, int NREG>
+__device__ int march_ray_blocked(const DevScene &S, const LiArgs &A, const pvol_ray &pr, Rng &rng, MarchLds &M, int lane,
+                                 WaveCounters &wc, f4 *LvOut, f4 *TrOut, RayRec rec) {
+    static_assert(MODE == MODE_PAR || MODE == MODE_REPLAY, "ray-parallel modes only");
+    if (S.volKind == PVOL_VOLUME_GRID || S.volKind == PVOL_VOLUME_NONE || A.transmittanceOnly) return 2;
+    const int q = lane & 7;
+    const f4 sigA = ld4(S.sigA, q), sigS = ld4(S.sigS, q);
+    const f4 sigT = sigA + sigS;
+    const f4 Y = ld4(S.cieY, q);
+    const int nLights = S.nLights;
+    const bool rainbow = (S.volKind == PVOL_VOLUME_RAINBOW);
+    RayD ray;
+    ray.o = v3(pr.o[0], pr.o[1], pr.o[2]);
+    ray.d = v3(pr.d[0], pr.d[1], pr.d[2]);
+    ray.mint = pr.mint;
+    ray.maxt = pr.maxt;
+    f4 Lv = mk4(0.f), Tr = mk4(1.f);
+    float t0, t1;
+    bool hit = vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
+    int nSamples = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
+    if (MODE == MODE_REPLAY && hit && nSamples > S.maxSteps) return 2;   // march_ray reports it
+    if (STATS) ++wc.rays;
+    int nEff = nSamples;
+    bool killed = false;
+    if (MODE == MODE_REPLAY) { nEff = (int)rec.hdr[0]; killed = (rec.hdr[1] & 1u) != 0u; }
+    if (hit) {
+        const float step = (t1 - t0) / nSamples;
+        const V3 pEntry = ray.o + ray.d * t0;
+        const V3 w = -ray.d;
+        float tcur = t0 + pr.scatter_u * step;
+        rng_skip<false>(rng, 4ull + 6ull * (unsigned long long)nSamples, lane);
+        const f4 le = ld4(S.le, q);
+        const float ySa1 = spec_y(sigA, Y), ySs1 = spec_y(sigS, Y);
+        const bool blackS1 = spec_is_black(sigS);
+        const f4 albedo1 = clean4(fdiv4(sigS, sigA + sigS), q);
+        // largest sigma_t bin: Tr.y() >= Y(1) * exp(-len * sigTmax), so the roulette (Tr.y() < 1e-3) cannot
+        // fire while len * sigTmax < 6.8
+        float sigTmax = fmaxf(fmaxf(sigT.x, sigT.y), fmaxf(sigT.z, sigT.w));
+        sigTmax = wave_max(sigTmax);
+        unsigned int lightBlackMask = 0u;   // lights whose intensity spectrum is black
+        for (int l = 0; l < nLights; ++l) if (spec_is_black(ld4(S.lights[l].intensity, q))) lightBlackMask |= 1u << l;
+        float lastRk = 0.f;
+        V3 pCarry = pEntry;                                                  // p of the step before the block
+        bool inCarry = box_inside(S.extLo, S.extHi, xform_point(S.w2v, pEntry));
+        for (int base = 0; base < nEff; base += LANES) {
+            const int cnt = min(LANES, nEff - base);
+            // t0 is ACCUMULATED in the reference (`t0 += step` per iteration): replay the same additions
+            float tMine = 0.f;
+            for (int j = 0; j < cnt; ++j) {
+                if (lane == j) tMine = tcur;
+                tcur += step;
+            }
+            const bool on = lane < cnt;
+            const V3 p = ray.o + ray.d * tMine;
+            const V3 pv = xform_point(S.w2v, p);
+            const bool inP = on && box_inside(S.extLo, S.extHi, pv);
+            // pPrev / inPrev of lane j = p / inP of lane j-1 (block carry for lane 0)
+            V3 pPrev;
+            pPrev.x = __shfl_up(p.x, 1); pPrev.y = __shfl_up(p.y, 1); pPrev.z = __shfl_up(p.z, 1);
+            int inPrevI = __shfl_up(inP ? 1 : 0, 1);
+            if (lane == 0) { pPrev = pCarry; inPrevI = inCarry ? 1 : 0; }
+            const bool inPrev = inPrevI != 0;
+            float lenStep;
+            {
+                V3 dseg = p - pPrev;
+                if (inPrev && inP) {
+                    V3 a = pPrev + dseg * 0.f, b = pPrev + dseg * 1.f;
+                    lenStep = len(a - b);
+                } else {
+                    lenStep = analytic_tau_length(S, pPrev, dseg, 0.f, 1.f);
+                }
+            }
+            // carry for the next block
+            pCarry.x = __shfl(p.x, cnt - 1); pCarry.y = __shfl(p.y, cnt - 1); pCarry.z = __shfl(p.z, cnt - 1);
+            inCarry = __shfl(inP ? 1 : 0, cnt - 1) != 0;
+            if (wave_any(on && !(lenStep * sigTmax < 6.8f))) {
+                if (MODE == MODE_PAR) return 1;
+            }
+            // direct lighting geometry of this lane's step
+            unsigned int recByte = 0u;
+            if (MODE == MODE_REPLAY && on) recByte = rec.stepByte[base + lane];
+            const int ln = (MODE == MODE_REPLAY) ? (int)(recByte & 7u) : 0;
+            float fallReg = 1.f, d2Reg = 1.f, exitLen = 0.f, ph = 0.f;
+            V3 wo = v3(0.f, 0.f, 0.f);
+            bool lit = false;
+            if (on && inP && !blackS1 && nLights > 0) {   // dens == 1 inside, 0 outside: sigma_s is black outside
+                const DevLight &light = S.lights[ln];
+                RayD vis;
+                if (light.kind == PVOL_LIGHT_DISTANT) {   // distant.cpp:48-55
+                    wo = v3(light.dir[0], light.dir[1], light.dir[2]);
+                    vis.o = p; vis.d = wo; vis.mint = 0.f; vis.maxt = INFINITY;
+                } else {                                  // point.cpp:50-57, spot.cpp:50-57
+                    V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
+                    wo = normalize(lp - p);
+                    float dist = len(p - lp);
+                    vis.o = p; vis.d = vdiv(lp - p, dist); vis.mint = 0.f; vis.maxt = dist * (1.f - 0.f);
+                    d2Reg = len_sq(lp - p);
+                    if (light.kind == PVOL_LIGHT_SPOT) {  // SpotLight::Falloff(-wi), spot.cpp:60-69
+                        V3 wl = normalize(v3(light.w2l[0] * -wo.x + light.w2l[1] * -wo.y + light.w2l[2] * -wo.z,
+                                             light.w2l[4] * -wo.x + light.w2l[5] * -wo.y + light.w2l[6] * -wo.z,
+                                             light.w2l[8] * -wo.x + light.w2l[9] * -wo.y + light.w2l[10] * -wo.z));
+                        float costheta = wl.z;
+                        if (costheta < light.cosTotalWidth) fallReg = 0.f;
+                        else if (costheta > light.cosFalloffStart) fallReg = 1.f;
+                        else {
+                            float delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+                            fallReg = delta * delta * delta * delta;
+                        }
+                    }
+                }
+                // L.IsBlack(): I * fall / d2 has no non-zero bin
+                const bool black = (fallReg == 0.f) || ((lightBlackMask >> ln) & 1u);
+                if (!black && !lane_occluded(S, vis)) {
+                    lit = true;
+                    V3 dv = xform_vector(S.w2v, vis.d);
+                    V3 dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
+                    exitLen = inside_exit_length(S, vis.o, vis.d, pv, dvInv, vis.maxt);
+                    ph = phase_hg(w, -wo, S.g);
+                }
+            }
+            // draws of the block: one tau() offset per step + one per lit shadow ray (roulette excluded above)
+            rng.draws += (unsigned long long)cnt + (unsigned long long)__popcll(__ballot(lit));
+            if (STATS) { wc.steps += cnt; wc.unocc += __popcll(__ballot(lit)); }
+            // ---- serial part: spectral arithmetic + gather, one step at a time
+            for (int j = 0; j < cnt; ++j) {
+                const float lenJ = __shfl(lenStep, j);
+                const bool inJ = __shfl(inP ? 1 : 0, j) != 0;
+                const bool litJ = __shfl(lit ? 1 : 0, j) != 0;
+                const V3 pJ = v3(__shfl(p.x, j), __shfl(p.y, j), __shfl(p.z, j));
+                Tr = exp4(neg4(sigT * lenJ));   // assigned, not accumulated (photonvolume.cpp:155)
+                if (MODE == MODE_REPLAY) {
+                    const unsigned int rb = __shfl((int)recByte, j);
+                    if (rb & 0x80u) Tr = Tr / .5f;
+                }
+                const float dens = inJ ? 1.f : 0.f;
+                f4 ss = sigS * dens, sa = sigA * dens;
+                f4 L_d = mk4(0.f), L_ii = mk4(0.f), L_i;
+                if (litJ) {
+                    const int lnJ = (MODE == MODE_REPLAY) ? (__shfl((int)recByte, j) & 7) : 0;
+                    const DevLight &light = S.lights[lnJ];
+                    f4 L = ld4(light.intensity, q);
+                    if (light.kind != PVOL_LIGHT_DISTANT) L = L * __shfl(fallReg, j) / __shfl(d2Reg, j);
+                    f4 Ttr = exp4(neg4(sigT * __shfl(exitLen, j)));
+                    f4 Ld = L * Ttr;
+                    if (rainbow) {
+                        V3 woJ = v3(__shfl(wo.x, j), __shfl(wo.y, j), __shfl(wo.z, j));
+                        L_d = rainbow_reflection(Ld, ray.d, woJ, q);
+                    } else {
+                        L_d = Ld * __shfl(ph, j) * float(nLights) / 1.f;
+                    }
+                }
+                if (!rainbow) {
+                    const int i = base + j;
+                    float guess = i < PREV_N ? fmaxf(M.prevRk[i], lastRk) : lastRk;
+                    float rk;
+                    L_ii = lphoton<STATS, NREG>(S, M.G, w, pJ, ss, lane, wc, guess, &rk);
+                    lastRk = rk;
+                    if (i < PREV_N && lane == 0) M.prevRk[i] = rk;
+                }
+                if (inJ ? (ySa1 != 0.0 || ySs1 != 0.0) : false) L_i = L_d + albedo1 * L_ii;
+                else L_i = L_d;
+                Lv = (sa * (le * dens) * step) + (ss * L_i * step) + (Tr * Lv);
+            }
+        }
+        if (MODE == MODE_REPLAY && killed) Tr = mk4(0.f);
+    }
+    *LvOut = Lv;
+    *TrOut = Tr;
+    return 0;
+}
+
 __device__ __forceinline__ void write_outputs(const DevScene &S, const LiArgs &A, size_t ri, f4 Lv, f4 Tr, int lane) {
     const int q = lane & 7;
     if (A.outputKind == PVOL_OUT_SPECTRAL) {
@@ -841,7 +1034,9 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
             rng.draws = 0;
             f4 Lv, Tr;
             RayRec none = {0, 0, 0};
-            bool okRay = march_ray<STATS, MODE_PAR, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, none);
+            int brc = march_ray_blocked<STATS, MODE_PAR, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, none);
+            bool okRay = (brc == 0);
+            if (brc == 2) { rng.draws = 0; okRay = march_ray<STATS, MODE_PAR, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, none); }
             if (!okRay) {
                 if (lane == 0) atomicOr(A.needSeq, 1u);
                 continue;
@@ -953,7 +1148,8 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_replay_kernel(LiArgs A) {
             const pvol_ray pr = A.rays[ri];
             RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + l) * A.recStride, S.maxSteps, grid);
             f4 Lv, Tr;
-            march_ray<STATS, MODE_REPLAY, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
+            if (march_ray_blocked<STATS, MODE_REPLAY, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec) == 2)
+                march_ray<STATS, MODE_REPLAY, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
             write_outputs(S, A, ri, Lv, Tr, lane);
         }
     }

@@ -371,8 +371,8 @@ int pvol_download_photons(pvol_ctx *c, float *p, float *wi, float *alpha, uint32
 }
 
 // LDS plans of the two kernels (pvol_march.hip)
-static size_t lds_bytes_seq(const pvol_ctx *c) { return 624 * 4 + (size_t)c->hs.candCap * 8 + (size_t)c->hs.maxSteps * 4 + 256 * 4; }
-static size_t lds_bytes_par(const pvol_ctx *c) { return (size_t)c->hs.candCap * 8 + 256 * 4; }
+static size_t lds_bytes_seq(const pvol_ctx *c) { return 624 * 4 + (size_t)c->hs.candCap * 8 + (size_t)c->hs.maxSteps * 4 + 256 * 4 + 1024 * 4; }
+static size_t lds_bytes_par(const pvol_ctx *c) { return (size_t)c->hs.candCap * 8 + 256 * 4 + 1024 * 4; }
 
 // Drawn VALUES cannot reach Li()'s result with at most one light and an analytic tau():
 // such scenes take the ray-parallel kernel, backed by the sequential one if a ray reaches the roulette.

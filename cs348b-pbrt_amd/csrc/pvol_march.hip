@@ -29,6 +29,11 @@
 #define NCH 4        // chunks of 64 candidate loads in flight
 #define PREV_N 256   // march steps for which the previous ray's k-th distance^2 is remembered
 #define CHUNK_RAYS 64
+#ifndef PVOL_GUESS_SCALE
+#define PVOL_GUESS_SCALE 1.3f   // first search radius^2 = this x the neighbouring k-th distance^2
+#endif
+#define PAINT_ROW 16   // rows up to this many photons go through the painted index list
+#define PAINT_CAP (64 * PAINT_ROW)
 #ifndef PVOL_WPE
 #define PVOL_WPE 3   // minimum waves per SIMD the register allocator must leave room for (3 measured best: profiles/)
 #endif
@@ -107,6 +112,7 @@ template <bool SEQ> __device__ __forceinline__ void rng_skip(Rng &r, unsigned lo
 struct Gather {
     float *cd;      // LDS: candidate dist^2
     uint32_t *ci;   // LDS: candidate photon index (sorted order)
+    uint32_t *paint; // LDS: PAINT_CAP photon indices of the short rows, in concatenated order
     int cap;
 };
 // per-wave work counters (stats build), flushed with one atomic each when the wave retires
@@ -190,7 +196,7 @@ __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, i
     float T = S.maxDistSq;
     bool guessed = false;
     if (guess > 0.f) {
-        float Tg = guess * 1.5f;
+        float Tg = guess * PVOL_GUESS_SCALE;
         if (Tg < T) { T = Tg; guessed = true; }
     }
     int count = 0;
@@ -223,62 +229,85 @@ __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, i
                 start = S.cellStart[base + x0];
                 rlen = S.cellStart[base + x1 + 1] - start;
             }
-            uint32_t incl = rlen;   // exclusive scan of the row lengths over the wave
-#pragma unroll
-            for (int d = 1; d < LANES; d <<= 1) {
-                uint32_t v = __shfl_up(incl, d);
-                if (lane >= d) incl += v;
-            }
-            const uint32_t off = incl - rlen;
-            const uint32_t total = __shfl(incl, LANES - 1);
+            // ---- short rows (<= PAINT_ROW photons, the usual case): their photon indices are PAINTED into an LDS
+            // list in concatenated order -- lane j writes start_j + it at off_j + it -- so that the candidate
+            // loop below is one LDS read per 64 candidates instead of a per-lane search for "which row am I in"
+            const uint32_t lenS = rlen <= PAINT_ROW ? rlen : 0u;
+            // inclusive scan of the row lengths over the wave with DPP adds (no LDS round trips):
+            // row_shr 1,2,4,8 scan each row of 16 lanes, row_bcast15/31 carry the row totals across rows
+            uint32_t incl = lenS;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+            const uint32_t off = incl - lenS;
+            const uint32_t total = (uint32_t)lane_i((int)incl, LANES - 1);   // <= 64 * PAINT_ROW == PAINT_CAP
             if (STATS) tested += total;
-            for (uint32_t cb = 0; cb < total; cb += LANES * NCH) {
-                f4 P[NCH];
-                uint32_t I[NCH];
-                bool on[NCH];
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    on[c] = false;
-                    I[c] = 0u;
-                    P[c] = mk4(0.f);
-                    if (cb + c * LANES < total) {   // wave-uniform
-                        uint32_t g = cb + c * LANES + lane;
-                        on[c] = g < total;
-                        int lo = 0, hi = LANES;     // row of element g: the largest lane j with off_j <= g
-#pragma unroll
-                        for (int it = 0; it < 6; ++it) {
-                            int mid = (lo + hi) >> 1;
-                            uint32_t v = __shfl(off, mid);
-                            if (v <= g) lo = mid; else hi = mid;
-                        }
-                        I[c] = __shfl(start, lo) + (g - __shfl(off, lo));
-                        if (on[c]) P[c] = S.pos4[I[c]];
-                    }
+            uint64_t longRows = __ballot(rlen > PAINT_ROW);
+            if (total) {
+                __syncthreads();
+                for (uint32_t it = 0; it < PAINT_ROW; ++it) {
+                    if (!wave_any(it < lenS)) break;
+                    if (it < lenS) G.paint[off + it] = start + it;
                 }
+                __syncthreads();
+            }
+            // candidate segments: first the painted list, then every long row by itself (contiguous photons)
+            uint32_t segBase = 0u, segLen = total;
+            bool painted = true;
+            for (;;) {
+                for (uint32_t cb = 0; cb < segLen; cb += LANES * NCH) {
+                    f4 P[NCH];
+                    uint32_t I[NCH];
+                    bool on[NCH];
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (cb + c * LANES >= total) continue;   // wave-uniform
-                    float dx = P[c].x - pt.x, dyy = P[c].y - pt.y, dzz = P[c].z - pt.z;
-                    float d2 = dx * dx + dyy * dyy + dzz * dzz;   // DistanceSquared(photon.p, p), kdtree.h:180
-                    bool acc = on[c] && d2 < T;
-                    uint64_t m = __ballot(acc);
-                    if (m) {
-                        if (acc) {
-                            int pos = count + (int)lanes_below(m, lane);
-                            G.cd[pos] = d2;
-                            G.ci[pos] = I[c];
-                        }
-                        count += __popcll(m);
-                        __syncthreads();
-                        if (count > G.cap - LANES) {
-                            unsigned long long ts = 0;
-                            if (STATS) ts = stamp();
-                            T = select_k<NREG>(G, count, k, T, lane);
-                            if (STATS) selCy += stamp() - ts;
-                            count = k;
+                    for (int c = 0; c < NCH; ++c) {
+                        on[c] = false;
+                        I[c] = 0u;
+                        P[c] = mk4(0.f);
+                        if (cb + c * LANES < segLen) {   // wave-uniform
+                            uint32_t g = cb + c * LANES + lane;
+                            on[c] = g < segLen;
+                            if (on[c]) {
+                                I[c] = painted ? G.paint[g] : segBase + g;
+                                P[c] = S.pos4[I[c]];
+                            }
                         }
                     }
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (cb + c * LANES >= segLen) continue;   // wave-uniform
+                        float dx = P[c].x - pt.x, dyy = P[c].y - pt.y, dzz = P[c].z - pt.z;
+                        float d2 = dx * dx + dyy * dyy + dzz * dzz;   // DistanceSquared(photon.p, p), kdtree.h:180
+                        bool acc = on[c] && d2 < T;
+                        uint64_t m = __ballot(acc);
+                        if (m) {
+                            if (acc) {
+                                int pos = count + (int)lanes_below(m, lane);
+                                G.cd[pos] = d2;
+                                G.ci[pos] = I[c];
+                            }
+                            count += __popcll(m);
+                            __syncthreads();
+                            if (count > G.cap - LANES) {
+                                unsigned long long ts = 0;
+                                if (STATS) ts = stamp();
+                                T = select_k<NREG>(G, count, k, T, lane);
+                                if (STATS) selCy += stamp() - ts;
+                                count = k;
+                            }
+                        }
+                    }
                 }
+                if (!longRows) break;
+                const int j = __ffsll((unsigned long long)longRows) - 1;
+                longRows &= longRows - 1;
+                painted = false;
+                segBase = (uint32_t)lane_i((int)start, j);
+                segLen = (uint32_t)lane_i((int)rlen, j);
+                if (STATS) tested += segLen;
             }
         }
         if (guessed && count < k) {   // the guessed radius held fewer than k photons: search the full radius
@@ -342,9 +371,10 @@ __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, i
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = acc + a[j] * wg[j];
     }
-    acc.x += __shfl_xor(acc.x, 8); acc.y += __shfl_xor(acc.y, 8); acc.z += __shfl_xor(acc.z, 8); acc.w += __shfl_xor(acc.w, 8);
-    acc.x += __shfl_xor(acc.x, 16); acc.y += __shfl_xor(acc.y, 16); acc.z += __shfl_xor(acc.z, 16); acc.w += __shfl_xor(acc.w, 16);
-    acc.x += __shfl_xor(acc.x, 32); acc.y += __shfl_xor(acc.y, 32); acc.z += __shfl_xor(acc.z, 32); acc.w += __shfl_xor(acc.w, 32);
+    // sum the 8 photon groups (lanes l, l^8, l^16, l^32 ...): DPP row rotate, then the two permlane swaps
+    acc.x += dppf<DPP_ROW_ROR8>(acc.x); acc.y += dppf<DPP_ROW_ROR8>(acc.y); acc.z += dppf<DPP_ROW_ROR8>(acc.z); acc.w += dppf<DPP_ROW_ROR8>(acc.w);
+    acc.x = xor16_sum(acc.x); acc.y = xor16_sum(acc.y); acc.z = xor16_sum(acc.z); acc.w = xor16_sum(acc.w);
+    acc.x = xor32_sum(acc.x); acc.y = xor32_sum(acc.y); acc.z = xor32_sum(acc.z); acc.w = xor32_sum(acc.w);
     float distSq = maxmd;
     float dV = distSq * sqrtf(distSq);
     f4 L = zero;
@@ -785,8 +815,8 @@ __device__ int march_ray_blocked(const DevScene &S, const LiArgs &A, const pvol_
                 }
             }
             // carry for the next block
-            pCarry.x = __shfl(p.x, cnt - 1); pCarry.y = __shfl(p.y, cnt - 1); pCarry.z = __shfl(p.z, cnt - 1);
-            inCarry = __shfl(inP ? 1 : 0, cnt - 1) != 0;
+            pCarry.x = lane_f(p.x, cnt - 1); pCarry.y = lane_f(p.y, cnt - 1); pCarry.z = lane_f(p.z, cnt - 1);
+            inCarry = lane_i(inP ? 1 : 0, cnt - 1) != 0;
             if (wave_any(on && !(lenStep * sigTmax < 6.8f))) {
                 if (MODE == MODE_PAR) return 1;
             }
@@ -837,30 +867,30 @@ __device__ int march_ray_blocked(const DevScene &S, const LiArgs &A, const pvol_
             if (STATS) { wc.steps += cnt; wc.unocc += __popcll(__ballot(lit)); }
             // ---- serial part: spectral arithmetic + gather, one step at a time
             for (int j = 0; j < cnt; ++j) {
-                const float lenJ = __shfl(lenStep, j);
-                const bool inJ = __shfl(inP ? 1 : 0, j) != 0;
-                const bool litJ = __shfl(lit ? 1 : 0, j) != 0;
-                const V3 pJ = v3(__shfl(p.x, j), __shfl(p.y, j), __shfl(p.z, j));
+                const float lenJ = lane_f(lenStep, j);
+                const bool inJ = lane_i(inP ? 1 : 0, j) != 0;
+                const bool litJ = lane_i(lit ? 1 : 0, j) != 0;
+                const V3 pJ = v3(lane_f(p.x, j), lane_f(p.y, j), lane_f(p.z, j));
                 Tr = exp4(neg4(sigT * lenJ));   // assigned, not accumulated (photonvolume.cpp:155)
                 if (MODE == MODE_REPLAY) {
-                    const unsigned int rb = __shfl((int)recByte, j);
+                    const unsigned int rb = (unsigned int)lane_i((int)recByte, j);
                     if (rb & 0x80u) Tr = Tr / .5f;
                 }
                 const float dens = inJ ? 1.f : 0.f;
                 f4 ss = sigS * dens, sa = sigA * dens;
                 f4 L_d = mk4(0.f), L_ii = mk4(0.f), L_i;
                 if (litJ) {
-                    const int lnJ = (MODE == MODE_REPLAY) ? (__shfl((int)recByte, j) & 7) : 0;
+                    const int lnJ = (MODE == MODE_REPLAY) ? (lane_i((int)recByte, j) & 7) : 0;
                     const DevLight &light = S.lights[lnJ];
                     f4 L = ld4(light.intensity, q);
-                    if (light.kind != PVOL_LIGHT_DISTANT) L = L * __shfl(fallReg, j) / __shfl(d2Reg, j);
-                    f4 Ttr = exp4(neg4(sigT * __shfl(exitLen, j)));
+                    if (light.kind != PVOL_LIGHT_DISTANT) L = L * lane_f(fallReg, j) / lane_f(d2Reg, j);
+                    f4 Ttr = exp4(neg4(sigT * lane_f(exitLen, j)));
                     f4 Ld = L * Ttr;
                     if (rainbow) {
-                        V3 woJ = v3(__shfl(wo.x, j), __shfl(wo.y, j), __shfl(wo.z, j));
+                        V3 woJ = v3(lane_f(wo.x, j), lane_f(wo.y, j), lane_f(wo.z, j));
                         L_d = rainbow_reflection(Ld, ray.d, woJ, q);
                     } else {
-                        L_d = Ld * __shfl(ph, j) * float(nLights) / 1.f;
+                        L_d = Ld * lane_f(ph, j) * float(nLights) / 1.f;
                     }
                 }
                 if (!rainbow) {
@@ -923,7 +953,7 @@ __device__ __forceinline__ void flush_counters(DevCounters *c, const WaveCounter
     }
 }
 
-// LDS plan (bytes): [MT 2496 (SEQ)] | cand d2 cap*4 | cand idx cap*4 | lightNum maxSteps*4 (SEQ) | prevRk PREV_N*4
+// LDS plan (bytes): [MT 2496 (SEQ)] | cand d2 cap*4 | cand idx cap*4 | lightNum maxSteps*4 (SEQ) | prevRk PREV_N*4 | paint PAINT_CAP*4
 template <bool STATS, int NREG>
 __global__ __launch_bounds__(LANES, PVOL_WPE) void li_seq_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -939,6 +969,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_seq_kernel(LiArgs A) {
     M.G.ci = reinterpret_cast<uint32_t *>(lds + MT_N * 4 + (size_t)M.G.cap * 4);
     M.lightNum = reinterpret_cast<float *>(lds + MT_N * 4 + (size_t)M.G.cap * 8);
     M.prevRk = M.lightNum + S.maxSteps;
+    M.G.paint = reinterpret_cast<uint32_t *>(M.prevRk + PREV_N);
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
     __syncthreads();
 
@@ -1006,6 +1037,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
     M.G.ci = reinterpret_cast<uint32_t *>(lds + (size_t)M.G.cap * 4);
     M.lightNum = 0;
     M.prevRk = reinterpret_cast<float *>(lds + (size_t)M.G.cap * 8);
+    M.G.paint = reinterpret_cast<uint32_t *>(M.prevRk + PREV_N);
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
     __syncthreads();
     Rng rng;
@@ -1016,7 +1048,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
     for (;;) {
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(A.chunkCounter, 1u);
-        chunk = __shfl(chunk, 0);
+        chunk = (uint32_t)lane_i((int)chunk, 0);
         unsigned long long r0 = (unsigned long long)chunk * CHUNK_RAYS;
         if (r0 >= A.nRays) break;
         uint32_t r1 = (uint32_t)min((unsigned long long)A.nRays, r0 + CHUNK_RAYS);
@@ -1061,7 +1093,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_resolve_kernel(LiArgs A) {
     if (sidx >= A.nStreams) return;
     uint32_t *mt = reinterpret_cast<uint32_t *>(lds);
     MarchLds M;
-    M.G.cap = 0; M.G.cd = 0; M.G.ci = 0;
+    M.G.cap = 0; M.G.cd = 0; M.G.ci = 0; M.G.paint = 0;
     M.lightNum = reinterpret_cast<float *>(lds + MT_N * 4);
     M.prevRk = 0;
     pvol_stream st = A.streams[sidx];
@@ -1119,6 +1151,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_replay_kernel(LiArgs A) {
     M.G.ci = reinterpret_cast<uint32_t *>(lds + (size_t)M.G.cap * 4);
     M.lightNum = 0;
     M.prevRk = reinterpret_cast<float *>(lds + (size_t)M.G.cap * 8);
+    M.G.paint = reinterpret_cast<uint32_t *>(M.prevRk + PREV_N);
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
     __syncthreads();
     Rng rng;
@@ -1133,7 +1166,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_replay_kernel(LiArgs A) {
     for (;;) {
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(A.chunkCounter, 1u);
-        chunk = __shfl(chunk, 0);
+        chunk = (uint32_t)lane_i((int)chunk, 0);
         if (chunk >= nChunks) break;
         const uint32_t sidx = chunk / chunksPerSlice, j = chunk - sidx * chunksPerSlice;
         const uint32_t nr = A.streams[sidx].n_rays, first = A.streams[sidx].first_ray;

@@ -35,15 +35,51 @@ __device__ __forceinline__ f4 fdiv4(f4 a, f4 b) {
 __device__ __forceinline__ f4 clean4(f4 a, int q) { if (q == 7) { a.z = 0.f; a.w = 0.f; } return a; }
 __device__ __forceinline__ f4 ld4(const float *base32, int q) { return *reinterpret_cast<const f4 *>(base32 + 4 * q); }
 
+// ---- cross-lane helpers on DPP / v_readlane / v_permlane*_swap: no LDS crossbar round trips.
+// (`__shfl*` lowers to ds_bpermute_b32, ~100+ cycles of dependent latency each.)
+#define DPP_QUAD_XOR1 0xB1        /* quad_perm [1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E        /* quad_perm [2,3,0,1] */
+#define DPP_ROW_HALF_MIRROR 0x141 /* lane i <-> 7 - i inside each group of 8 */
+#define DPP_ROW_ROR8 0x128        /* lane i <- lane (i + 8) mod 16 inside each row of 16 */
+template <int CTRL> __device__ __forceinline__ float dppf(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// value of a wave-uniform lane
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int lane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+// sum over the 8 lanes of a group (every lane of the group gets it)
 __device__ __forceinline__ float group8_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
+    v += dppf<DPP_QUAD_XOR1>(v);
+    v += dppf<DPP_QUAD_XOR2>(v);
+    v += dppf<DPP_ROW_HALF_MIRROR>(v);   // after the two quad steps every lane of a quad holds the quad sum
     return v;
 }
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] in every lane: gfx950 v_permlane16_swap / v_permlane32_swap exchange
+// odd/even rows (resp. halves) of two registers; with both operands equal the two results are the partners
+__device__ __forceinline__ float xor16_sum(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_max(float v) {
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 __device__ __forceinline__ bool wave_any(bool p) { return __ballot(p) != 0ull; }
-__device__ __forceinline__ float wave_max(float v) {
-    for (int m = 1; m < LANES; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+__device__ __forceinline__ float wave_max(float v) {   // every lane gets the maximum over the wave
+    v = fmaxf(v, dppf<DPP_QUAD_XOR1>(v));
+    v = fmaxf(v, dppf<DPP_QUAD_XOR2>(v));
+    v = fmaxf(v, dppf<DPP_ROW_HALF_MIRROR>(v));
+    v = fmaxf(v, dppf<DPP_ROW_ROR8>(v));
+    v = xor16_max(v);
+    v = xor32_max(v);
     return v;
 }
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {

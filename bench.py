@@ -141,29 +141,31 @@ def cpu_baseline(scene, params, photons, xres, yres, budget_s=15.0):
     t0 = time.time()
     o.set_photons(*photons)
     t_build = time.time() - t0
+    # whole render tiles of the same frame, picked at random, same ray generator (incl. the surface clip) as the GPU pass
+    import torch
+    x0s, x1s, y0s, y1s, n_tiles = frame_tiles(xres, yres)
     rng = np.random.default_rng(1)
-    tan = math.tan(math.radians(float(scene["camera.fov"][0])) / 2)
-    aspect = xres / float(yres)
-    per_stream = 64
     n_streams = cores * 2
+    spp = 1
     done, elapsed = 0, 0.0
     while elapsed < budget_s:
-        n = per_stream * n_streams
-        X, Y = rng.random(n) * xres, rng.random(n) * yres
-        d = np.stack([(2 * X / xres - 1) * aspect * tan, (1 - 2 * Y / yres) * tan, np.ones(n)], 1)
-        d /= np.linalg.norm(d, axis=1, keepdims=True)
-        rays = abi.make_rays(np.zeros((n, 3), np.float32), d.astype(np.float32), 0.0, np.inf, rng.random(n).astype(np.float32))
-        st = abi.make_streams(np.arange(n_streams, dtype=np.uint32), np.full(n_streams, per_stream, np.uint32))
+        pick = rng.choice(n_tiles, n_streams, replace=False)
+        rays_t, counts = build_rays(torch, torch.device("cpu"), scene, xres, yres, spp, (x0s[pick], x1s[pick], y0s[pick], y1s[pick]),
+                                    seed=int(rng.integers(1 << 30)))
+        rn = rays_t.numpy()
+        rays = np.zeros(len(rn), abi.RAY_DTYPE)
+        rays["o"], rays["mint"], rays["d"], rays["maxt"], rays["time"], rays["scatter_u"] = rn[:, 0:3], rn[:, 3], rn[:, 4:7], rn[:, 7], rn[:, 8], rn[:, 9]
+        st = abi.make_streams(pick.astype(np.uint32), counts.astype(np.uint32))
         t0 = time.time()
         o.li_batch(rays, st, abi.OUT_XYZ, n_threads=cores)
         dt = time.time() - t0
-        done += n
+        done += len(rays)
         elapsed += dt
-        if dt < 1.0:
-            per_stream *= 2
+        if dt < 2.0:
+            spp *= 2
     ctr = o.counters()
     return {"value": done / elapsed / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%d Li() calls (random pixels of the same frame, same scene/photon map/params, kd-tree gather as core/kdtree.h), "
+            "sample": "%d Li() calls (random whole render tiles of the same frame, same ray generator/scene/photon map/params; kd-tree gather as core/kdtree.h), "
                       "%.1f s; kd build %.1f s; V=%.0f nodes, K=%.1f photons per lookup" %
                       (done, elapsed, t_build, ctr["n_nodes_visited"] / max(1, ctr["n_lookups"]), ctr["n_kept"] / max(1, ctr["n_lookups"]))}, ctr
 

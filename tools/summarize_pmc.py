@@ -18,7 +18,11 @@ os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
 
 agg = collections.defaultdict(float)
-for f in sorted(glob.glob(os.path.join(g, tag + "_pmc_*", "*", "*counter_collection.csv"))):
+for d in sorted(glob.glob(os.path.join(g, tag + "_pmc_*"))):
+    files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+    if not os.path.isdir(d) or not files:
+        continue
+    f = max(files, key=os.path.getmtime)   # gpurun merges runs: keep the newest pass only
     for r in csv.DictReader(open(f)):
         if "li_par_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
@@ -45,7 +49,8 @@ if agg and plain:
                "source": "profiles/%s_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 / rays, rocprofv3 --pmc passes of tools/pvol_prof" % tag},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("hbm bytes/ray %.0f, L2 hit %.3f, VALU insts/ray %.0f" % (hbm / rays, summary["l2_hit_rate"], agg.get("SQ_INSTS_VALU", 0) / rays))
-for f in glob.glob(os.path.join(g, tag + "_trace", "*", "*kernel_stats.csv")):
+_ks = glob.glob(os.path.join(g, tag + "_trace", "*", "*kernel_stats.csv"))
+for f in ([max(_ks, key=os.path.getmtime)] if _ks else []):
     rows = list(csv.reader(open(f)))
     keep = [rows[0]] + [r for r in rows[1:] if not r[0].startswith("void at::") and "rocprim" not in r[0] and "anonymous" not in r[0]][:12]
     with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as fo:

@@ -2,6 +2,8 @@
 (see blob.py) into the POD structs.  No compute happens here."""
 import ctypes as C
 
+import math
+
 import numpy as np
 
 NBINS = 30
@@ -207,3 +209,93 @@ def make_streams(seeds, counts, start_draw=0):
     s["first_ray"] = first
     s["start_draw"] = start_draw
     return s
+
+
+# ---- tile driver (include/pvol.h: pvol_camera, pvol_film, pvol_sampler, pvol_render_debug)
+MAX_SAMPLE_ARRAYS = 16
+FILTER_TABLE_SIZE = 16
+
+
+class Camera(C.Structure):
+    _fields_ = [("raster_to_camera", C.c_float * 16), ("camera_to_world", C.c_float * 16),
+                ("shutter_open", C.c_float), ("shutter_close", C.c_float),
+                ("lens_radius", C.c_float), ("focal_distance", C.c_float)]
+
+
+class Film(C.Structure):
+    _fields_ = [("x_resolution", C.c_int32), ("y_resolution", C.c_int32),
+                ("filter_xwidth", C.c_float), ("filter_ywidth", C.c_float),
+                ("filter_table", C.c_float * (FILTER_TABLE_SIZE * FILTER_TABLE_SIZE))]
+
+
+class Sampler(C.Structure):
+    _fields_ = [("x_start", C.c_int32), ("x_end", C.c_int32), ("y_start", C.c_int32), ("y_end", C.c_int32),
+                ("pixel_samples", C.c_uint32), ("n_tasks", C.c_uint32),
+                ("n1d_count", C.c_uint32), ("n2d_count", C.c_uint32),
+                ("n1d", C.c_uint32 * MAX_SAMPLE_ARRAYS), ("n2d", C.c_uint32 * MAX_SAMPLE_ARRAYS),
+                ("tau_index", C.c_uint32), ("scatter_index", C.c_uint32)]
+
+
+class RenderDebug(C.Structure):
+    _fields_ = [("d_rays", C.c_void_p), ("d_image_xy", C.c_void_p), ("d_xyz", C.c_void_p), ("d_streams", C.c_void_p)]
+
+
+def make_camera(raster_to_camera, camera_to_world, shutter_open=0.0, shutter_close=1.0, lens_radius=0.0, focal_distance=1e30):
+    c = Camera()
+    for i, v in enumerate(np.asarray(raster_to_camera, np.float32).reshape(16)):
+        c.raster_to_camera[i] = float(v)
+    for i, v in enumerate(np.asarray(camera_to_world, np.float32).reshape(16)):
+        c.camera_to_world[i] = float(v)
+    c.shutter_open, c.shutter_close, c.lens_radius, c.focal_distance = shutter_open, shutter_close, lens_radius, focal_distance
+    return c
+
+
+def make_film(xres, yres, filter_table, xwidth=2.0, ywidth=2.0):
+    f = Film()
+    f.x_resolution, f.y_resolution, f.filter_xwidth, f.filter_ywidth = int(xres), int(yres), xwidth, ywidth
+    for i, v in enumerate(np.asarray(filter_table, np.float32).reshape(256)):
+        f.filter_table[i] = float(v)
+    return f
+
+
+def make_sampler(xres, yres, spp, n_tasks, xwidth=2.0, ywidth=2.0, n1d=(1, 1), n2d=(), tau_index=0, scatter_index=1):
+    """LDSampler over Film::GetSampleExtent (film/image.cpp:157-166) with the Sample layout
+    PhotonVolumeIntegrator::RequestSamples leaves when it is the only requester (photonvolume.cpp:9-13)."""
+    s = Sampler()
+    s.x_start = int(math.floor(0 + 0.5 - xwidth))
+    s.x_end = int(math.ceil(0 + 0.5 + xres + xwidth))
+    s.y_start = int(math.floor(0 + 0.5 - ywidth))
+    s.y_end = int(math.ceil(0 + 0.5 + yres + ywidth))
+    s.pixel_samples, s.n_tasks = int(spp), int(n_tasks)
+    s.n1d_count, s.n2d_count = len(n1d), len(n2d)
+    for i, v in enumerate(n1d):
+        s.n1d[i] = v
+    for i, v in enumerate(n2d):
+        s.n2d[i] = v
+    s.tau_index, s.scatter_index = tau_index, scatter_index
+    return s
+
+
+def perspective_camera(fov, xres, yres, camera_to_world):
+    """RasterToCamera of PerspectiveCamera (core/camera.cpp:83-102, core/transform.cpp:313-323) in fp32, for
+    bench/tests that have no reference camera object at hand; the shim copies the reference's own matrices."""
+    f32 = np.float32
+    frame = f32(xres) / f32(yres)
+    sw = [-frame, frame, f32(-1), f32(1)] if frame > 1 else [f32(-1), f32(1), f32(-1) / frame, f32(1) / frame]
+    n, f = f32(1e-2), f32(1000.0)
+    persp = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, f / (f - n), -f * n / (f - n)], [0, 0, 1, 0]], np.float32)
+    inv_tan = f32(1) / f32(math.tan(math.radians(fov) / 2))
+    cam_to_screen = (np.diag(np.array([inv_tan, inv_tan, 1, 1], np.float32)) @ persp).astype(np.float32)
+
+    def scale(x, y, z):
+        return np.diag(np.array([x, y, z, 1], np.float32))
+
+    def translate(x, y, z):
+        m = np.eye(4, dtype=np.float32)
+        m[:3, 3] = [x, y, z]
+        return m
+    screen_to_raster = (scale(f32(xres), f32(yres), 1) @ scale(f32(1) / (sw[1] - sw[0]), f32(1) / (sw[2] - sw[3]), 1)
+                        @ translate(-sw[0], -sw[3], 0)).astype(np.float32)
+    raster_to_screen = np.linalg.inv(screen_to_raster.astype(np.float64))
+    raster_to_camera = (np.linalg.inv(cam_to_screen.astype(np.float64)) @ raster_to_screen).astype(np.float32)
+    return make_camera(raster_to_camera, camera_to_world)

@@ -175,6 +175,25 @@ __device__ __forceinline__ bool tri_hit(const DevTri &tr, const RayD &ray) {
     if (t < ray.mint || t > ray.maxt) return false;
     return true;
 }
+// shapes/trianglemesh.cpp:116-160 (closest hit: t reported) for one triangle
+__device__ __forceinline__ bool tri_closest(const DevTri &tr, V3 o, V3 d, float mint, float maxt, float *tHit) {
+    V3 p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]), p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+    V3 e1 = p2 - p1, e2 = p3 - p1;
+    V3 s1 = cross(d, e2);
+    float divisor = dot(s1, e1);
+    if (divisor == 0.f) return false;
+    float invDivisor = 1.f / divisor;
+    V3 s = o - p1;
+    float b1 = dot(s, s1) * invDivisor;
+    if (b1 < 0.f || b1 > 1.f) return false;
+    V3 s2 = cross(s, e1);
+    float b2 = dot(d, s2) * invDivisor;
+    if (b2 < 0.f || b1 + b2 > 1.f) return false;
+    float t = dot(e2, s2) * invDivisor;
+    if (t < mint || t > maxt) return false;
+    *tHit = t;
+    return true;
+}
 // Scene::IntersectP (core/scene.h:57-61): one triangle per lane
 __device__ __forceinline__ bool scene_occluded(const DevScene &S, const RayD &ray, int lane) {
     bool hit = false;

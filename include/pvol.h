@@ -178,6 +178,44 @@ typedef struct pvol_stats {
     uint64_t reserved[3];
 } pvol_stats;
 
+/* ---- tile driver, SURVEY 8(f)-1: the caller of Li() (LD sampler, perspective camera) and its
+ * consumer (image film) on the device, so that a whole SamplerRendererTask (renderers/
+ * samplerrenderer.cpp:59-157) runs without leaving HBM.  Surface radiance is NOT computed here: the
+ * driver is exact for renders whose surface integrator adds nothing and draws nothing (Ls = Lvi). ---- */
+#define PVOL_MAX_SAMPLE_ARRAYS 16
+#define PVOL_FILTER_TABLE_SIZE 16
+#define PVOL_MAX_PIXEL_SAMPLES 1024
+
+typedef struct pvol_camera {     /* PerspectiveCamera (cameras/perspective.cpp:41-49, core/camera.cpp:83-102) */
+    float raster_to_camera[16];  /* ProjectiveCamera::RasterToCamera.m, row-major                 */
+    float camera_to_world[16];   /* Camera::CameraToWorld of a static camera (startTransform->m)  */
+    float shutter_open, shutter_close;
+    float lens_radius;           /* must be 0 (pinhole); the lens samples are still drawn          */
+    float focal_distance;
+} pvol_camera;
+
+typedef struct pvol_film {       /* ImageFilm with the full-frame crop window (film/image.cpp:37-75) */
+    int32_t x_resolution, y_resolution;
+    float filter_xwidth, filter_ywidth;              /* Filter::xWidth, yWidth                     */
+    float filter_table[PVOL_FILTER_TABLE_SIZE * PVOL_FILTER_TABLE_SIZE];  /* ImageFilm::filterTable */
+} pvol_film;
+
+typedef struct pvol_sampler {    /* LDSampler (samplers/lowdiscrepancy.cpp:40-80) + the Sample layout  */
+    int32_t x_start, x_end, y_start, y_end;          /* Film::GetSampleExtent (film/image.cpp:157-166) */
+    uint32_t pixel_samples;                          /* power of two, <= PVOL_MAX_PIXEL_SAMPLES    */
+    uint32_t n_tasks;                                /* taskCount of SamplerRenderer::Render (samplerrenderer.cpp:206-208) */
+    uint32_t n1d_count, n2d_count;                   /* Sample::n1D / n2D as the integrators requested them */
+    uint32_t n1d[PVOL_MAX_SAMPLE_ARRAYS], n2d[PVOL_MAX_SAMPLE_ARRAYS];
+    uint32_t tau_index, scatter_index;               /* positions in n1d of tauSampleOffset / scatterSampleOffset (photonvolume.cpp:9-13) */
+} pvol_sampler;
+
+typedef struct pvol_render_debug {   /* optional DEVICE buffers that receive the intermediate records, sized for all samples of the call */
+    pvol_ray *d_rays;            /* camera rays after Scene::Intersect clipped maxt, tile-major    */
+    float *d_image_xy;           /* 2 floats per sample: CameraSample::imageX, imageY              */
+    float *d_xyz;                /* 4 floats per sample: Lvi as X,Y,Z and T.y()                    */
+    pvol_stream *d_streams;      /* one per task of the call, end_draw filled                      */
+} pvol_render_debug;
+
 typedef struct pvol_ctx pvol_ctx;
 
 /* Version of this ABI (PVOL_ABI_VERSION). */
@@ -228,7 +266,9 @@ int pvol_download_photons(pvol_ctx *ctx, float *p, float *wi, float *alpha, uint
 /* Replaces PhotonVolumeIntegrator::Li (photonvolume.cpp:112-222) for a batch of rays
  * grouped into MT19937 streams.  Host pointers; `out` has n_rays*60 (SPECTRAL) or
  * n_rays*4 (XYZ) floats; `draws` (optional) receives per ray the number of RandomUInt
- * calls Li() made (4+6n+n+r+u).  streams[i].end_draw is written. */
+ * calls Li() made (4+6n+n+r+u).  streams[i].end_draw is written.
+ * The streams must partition the ray array in order: streams[0].first_ray == 0 and
+ * streams[i+1].first_ray == streams[i].first_ray + streams[i].n_rays (PVOL_E_INVALID otherwise). */
 int pvol_li_batch(pvol_ctx *ctx, const pvol_ray *rays, uint32_t n_rays,
                   pvol_stream *streams, uint32_t n_streams,
                   int output_kind, float *out, uint32_t *draws);
@@ -261,6 +301,36 @@ int pvol_enable_stats(pvol_ctx *ctx, int on);
 /* Average device time of the dominant (march+gather) kernel over the launches since
  * the last reset, measured with HIP events on the launch stream. */
 int pvol_kernel_time_ms(pvol_ctx *ctx, double *avg_ms, uint64_t *launches, int reset);
+
+/* GaussianFilter::Evaluate tabulated as ImageFilm's constructor does (filters/gaussian.h:44-58,
+ * film/image.cpp:57-68). */
+void pvol_gaussian_filter_table(float xwidth, float ywidth, float alpha, float *table256);
+
+/* Sampler::ComputeSubWindow (core/sampler.cpp:55-74) for task `task` of s->n_tasks: out = x0,x1,y0,y1. */
+void pvol_compute_sub_window(const pvol_sampler *s, uint32_t task, int32_t out[4]);
+
+/* Total camera samples of the given tasks (pixels of the sub-windows x pixel_samples). */
+uint64_t pvol_render_sample_count(const pvol_sampler *s, const uint32_t *task_ids, uint32_t n_task_ids);
+
+/* Runs SamplerRendererTask::Run (samplerrenderer.cpp:59-157) for the listed tasks: per task RNG(taskNum),
+ * LDSampler::GetMoreSamples -> LDPixelSample per pixel, PerspectiveCamera::GenerateRayDifferential,
+ * Scene::Intersect (clips the ray), PhotonVolumeIntegrator::Li, ImageFilm::AddSample.  d_pixels holds
+ * x_resolution*y_resolution*4 floats (Lxyz[3], weightSum as ImageFilm::Pixel) and is ACCUMULATED into,
+ * so ranks that render disjoint task sets sum their buffers (RCCL all-reduce) before pvol_film_resolve.
+ * Enqueued on hip_stream; work buffers live in the context. */
+int pvol_render_tasks_device(pvol_ctx *ctx, const pvol_camera *camera, const pvol_film *film,
+                             const pvol_sampler *sampler, const uint32_t *task_ids, uint32_t n_task_ids,
+                             float *d_pixels, const pvol_render_debug *debug, void *hip_stream);
+
+/* ImageFilm::AddSample (film/image.cpp:78-137) for n samples: d_image_xy 2 floats, d_xyz `xyz_stride`
+ * floats per sample (X,Y,Z first). */
+int pvol_film_add_samples_device(pvol_ctx *ctx, const pvol_film *film, const float *d_image_xy,
+                                 const float *d_xyz, uint32_t xyz_stride, uint64_t n,
+                                 float *d_pixels, void *hip_stream);
+
+/* ImageFilm::WriteRGB (film/image.cpp:178-214) without splats: d_rgb gets 3 floats per pixel. */
+int pvol_film_resolve_device(pvol_ctx *ctx, const pvol_film *film, const float *d_pixels, float *d_rgb,
+                             void *hip_stream);
 
 #ifdef __cplusplus
 }

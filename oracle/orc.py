@@ -70,6 +70,15 @@ def lib():
         L.orc_rainbow.argtypes = [_f32p, _f32p, _f32p, _f32p]
         L.orc_mc_samples.argtypes = [C.c_float, C.c_float, _f32p]
         L.orc_phase.argtypes = [C.c_float, _f32p]
+        L.orc_gaussian_filter_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
+        L.orc_compute_sub_window.argtypes = [C.POINTER(abi.Sampler), C.c_uint32, C.POINTER(C.c_int32)]
+        L.orc_ld_pixel_sample.argtypes = [C.POINTER(abi.Sampler), C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint32, C.c_uint64] + [_f32p] * 7
+        L.orc_ld_pixel_sample.restype = C.c_uint64
+        L.orc_camera_rays.argtypes = [C.POINTER(abi.Camera), _f32p, _f32p, C.c_uint32, C.c_void_p]
+        L.orc_film_add_samples.argtypes = [C.POINTER(abi.Film), _f32p, _f32p, C.c_uint32, C.c_uint64, _f32p]
+        L.orc_film_resolve.argtypes = [C.POINTER(abi.Film), _f32p, _f32p]
+        L.orc_render_tasks.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Film), C.POINTER(abi.Sampler), _u32p, C.c_uint32,
+                                       _f32p, C.c_void_p, _f32p, _f32p, _u64p, C.c_int]
         _lib = L
     return _lib
 
@@ -154,3 +163,65 @@ class Oracle:
         v = np.zeros(12, np.uint64)
         lib().orc_get_shoot_stats(self._h, _p(v, _u64p))
         return dict(zip(SHOOT_STAT_NAMES, [int(x) for x in v]))
+
+
+# ---- tile driver (orc_tile.h)
+def gaussian_filter_table(xw=2.0, yw=2.0, alpha=2.0):
+    t = np.zeros(256, np.float32)
+    lib().orc_gaussian_filter_table(xw, yw, alpha, _p(t, _f32p))
+    return t
+
+
+def sub_window(sampler, task):
+    w = (C.c_int32 * 4)()
+    lib().orc_compute_sub_window(C.byref(sampler), task, w)
+    return list(w)
+
+
+def ld_pixel_sample(sampler, x, y, seed, skip=0, shutter=(0.0, 1.0)):
+    n = sampler.pixel_samples
+    arrs = [np.zeros(n, np.float32) for _ in range(7)]
+    d = lib().orc_ld_pixel_sample(C.byref(sampler), x, y, shutter[0], shutter[1], seed, skip, *[_p(a, _f32p) for a in arrs])
+    return dict(zip(["imageX", "imageY", "time", "lensU", "lensV", "tau", "scatter"], arrs)), int(d)
+
+
+def camera_rays(camera, image_xy, time=None):
+    xy = np.ascontiguousarray(image_xy, np.float32).reshape(-1, 2)
+    out = np.zeros(len(xy), abi.RAY_DTYPE)
+    t = None if time is None else np.ascontiguousarray(time, np.float32)
+    lib().orc_camera_rays(C.byref(camera), _p(xy, _f32p), None if t is None else _p(t, _f32p), len(xy), out.ctypes.data)
+    return out
+
+
+def film_add_samples(film, image_xy, xyz, pixels=None):
+    xy = np.ascontiguousarray(image_xy, np.float32).reshape(-1, 2)
+    v = np.ascontiguousarray(xyz, np.float32)
+    if pixels is None:
+        pixels = np.zeros((film.y_resolution, film.x_resolution, 4), np.float32)
+    lib().orc_film_add_samples(C.byref(film), _p(xy, _f32p), _p(v, _f32p), v.shape[1], len(xy), _p(pixels, _f32p))
+    return pixels
+
+
+def film_resolve(film, pixels):
+    rgb = np.zeros((film.y_resolution, film.x_resolution, 3), np.float32)
+    px = np.ascontiguousarray(pixels, np.float32)
+    lib().orc_film_resolve(C.byref(film), _p(px, _f32p), _p(rgb, _f32p))
+    return rgb
+
+
+def render_tasks(oracle, camera, film, sampler, task_ids, records=True, n_threads=1):
+    """SamplerRendererTask::Run for the listed tasks -> dict(pixels, rays, image_xy, xyzT, end_draws)."""
+    ids = np.ascontiguousarray(task_ids, np.uint32)
+    n = 0
+    for t in ids:
+        w = sub_window(sampler, int(t))
+        n += (w[1] - w[0]) * (w[3] - w[2]) * sampler.pixel_samples
+    pixels = np.zeros((film.y_resolution, film.x_resolution, 4), np.float32)
+    rays = np.zeros(n if records else 0, abi.RAY_DTYPE)
+    xy = np.zeros((n if records else 0, 2), np.float32)
+    xt = np.zeros((n if records else 0, 4), np.float32)
+    end = np.zeros(len(ids), np.uint64)
+    lib().orc_render_tasks(oracle._h, C.byref(camera), C.byref(film), C.byref(sampler), _p(ids, _u32p), len(ids), _p(pixels, _f32p),
+                           rays.ctypes.data if records else None, _p(xy, _f32p) if records else None, _p(xt, _f32p) if records else None,
+                           _p(end, _u64p), n_threads)
+    return {"pixels": pixels, "rays": rays, "image_xy": xy, "xyzT": xt, "end_draws": end, "n_samples": n}

@@ -9,6 +9,7 @@
 
 #include "orc_integrator.h"
 #include "orc_shooter.h"
+#include "orc_tile.h"
 
 using namespace orc;
 
@@ -300,6 +301,99 @@ void orc_mc_samples(float u1, float u2, float *out) {
 void orc_phase(float c, float *out) {
     V3 w = v3(0, 0, 1), wp = v3(sqrtf(std::max(0.f, 1 - c * c)), 0, c);
     out[0] = phase_hg(w, wp, 0.f); out[1] = phase_hg(w, wp, 0.6f); out[2] = phase_hg(w, wp, -0.3f); out[3] = phase_mie_hazy(w, wp);
+}
+
+// ---------------------------------------------------------------- tile driver (orc_tile.h), SURVEY 8(f)-1
+void orc_gaussian_filter_table(float xw, float yw, float alpha, float *table256) { gaussian_filter_table(xw, yw, alpha, table256); }
+
+void orc_compute_sub_window(const pvol_sampler *s, uint32_t task, int32_t *out4) { compute_sub_window(*s, task, out4); }
+
+// LDPixelSample for one pixel from RNG(seed) advanced by `skip` draws; out arrays hold pixel_samples floats each
+uint64_t orc_ld_pixel_sample(const pvol_sampler *s, int xPos, int yPos, float shutterOpen, float shutterClose, uint32_t seed, uint64_t skip,
+                             float *imageX, float *imageY, float *time, float *lensU, float *lensV, float *tau, float *scatter) {
+    Rng rng(seed);
+    rng.skip(skip);
+    uint64_t d0 = rng.draws;
+    PixelSamples ps;
+    std::vector<float> buf;
+    ld_pixel_sample(xPos, yPos, shutterOpen, shutterClose, *s, ps, buf, rng);
+    size_t nb = sizeof(float) * s->pixel_samples;
+    memcpy(imageX, ps.imageX.data(), nb); memcpy(imageY, ps.imageY.data(), nb); memcpy(time, ps.time.data(), nb);
+    memcpy(lensU, ps.lensU.data(), nb); memcpy(lensV, ps.lensV.data(), nb); memcpy(tau, ps.tau.data(), nb); memcpy(scatter, ps.scatter.data(), nb);
+    return rng.draws - d0;
+}
+
+void orc_camera_rays(const pvol_camera *cam, const float *imageXY, const float *time, uint32_t n, pvol_ray *out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        Ray r = camera_ray(*cam, imageXY[2 * i], imageXY[2 * i + 1], time ? time[i] : 0.f);
+        pvol_ray &pr = out[i];
+        memset(&pr, 0, sizeof(pr));
+        pr.o[0] = r.o.x; pr.o[1] = r.o.y; pr.o[2] = r.o.z; pr.d[0] = r.d.x; pr.d[1] = r.d.y; pr.d[2] = r.d.z;
+        pr.mint = r.mint; pr.maxt = r.maxt; pr.time = r.time;
+    }
+}
+
+void orc_film_add_samples(const pvol_film *film, const float *imageXY, const float *xyz, uint32_t stride, uint64_t n, float *pixels) {
+    Film F;
+    F.f = *film;
+    size_t np = (size_t)4 * film->x_resolution * film->y_resolution;
+    F.pix.assign(pixels, pixels + np);
+    for (uint64_t i = 0; i < n; ++i) F.add_sample(imageXY[2 * i], imageXY[2 * i + 1], xyz + (size_t)stride * i);
+    memcpy(pixels, F.pix.data(), sizeof(float) * np);
+}
+
+void orc_film_resolve(const pvol_film *film, const float *pixels, float *rgb) {
+    Film F;
+    F.f = *film;
+    size_t np = (size_t)4 * film->x_resolution * film->y_resolution;
+    F.pix.assign(pixels, pixels + np);
+    F.write_rgb(rgb);
+}
+
+// SamplerRendererTask::Run for the listed tasks.  pixels (optional) is accumulated into in task order when
+// n_threads <= 1; with more threads every thread owns a film and they are summed at the end (bench baseline).
+// rays/imageXY/xyzT (optional, sized for all samples) receive the per-sample records in task order; end_draws
+// (optional) one per task.
+int orc_render_tasks(orc_ctx *c, const pvol_camera *cam, const pvol_film *film, const pvol_sampler *smp, const uint32_t *task_ids,
+                     uint32_t n_task_ids, float *pixels, pvol_ray *rays, float *imageXY, float *xyzT, uint64_t *end_draws, int n_threads) {
+    Integrator I = make_integrator(c);
+    const bool wantRec = rays || imageXY || xyzT;
+    std::vector<uint64_t> first(n_task_ids + 1, 0);
+    for (uint32_t i = 0; i < n_task_ids; ++i) {
+        int32_t w[4];
+        compute_sub_window(*smp, task_ids[i], w);
+        first[i + 1] = first[i] + (uint64_t)(w[1] - w[0]) * (uint64_t)(w[3] - w[2]) * smp->pixel_samples;
+    }
+    size_t np = pixels ? (size_t)4 * film->x_resolution * film->y_resolution : 0;
+    std::atomic<uint32_t> next(0);
+    std::mutex mu;
+    auto worker = [&](bool shared) {
+        Counters local;
+        Film F;
+        if (pixels) { F.f = *film; if (shared) F.pix.assign(pixels, pixels + np); else F.pix.assign(np, 0.f); }
+        for (;;) {
+            uint32_t i = next.fetch_add(1);
+            if (i >= n_task_ids) break;
+            std::vector<pvol_ray> r;
+            std::vector<float> xy, xt;
+            TileRecords rec = {&r, &xy, &xt};
+            uint64_t d = render_task(I, *cam, *smp, task_ids[i], pixels ? &F : 0, wantRec ? &rec : 0, &local);
+            if (end_draws) end_draws[i] = d;
+            if (rays) memcpy(rays + first[i], r.data(), sizeof(pvol_ray) * r.size());
+            if (imageXY) memcpy(imageXY + 2 * first[i], xy.data(), sizeof(float) * xy.size());
+            if (xyzT) memcpy(xyzT + 4 * first[i], xt.data(), sizeof(float) * xt.size());
+        }
+        std::lock_guard<std::mutex> g(mu);
+        c->ctr.add(local);
+        if (pixels) { if (shared) memcpy(pixels, F.pix.data(), sizeof(float) * np); else for (size_t k = 0; k < np; ++k) pixels[k] += F.pix[k]; }
+    };
+    if (n_threads <= 1) worker(true);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, false);
+        for (auto &t : th) t.join();
+    }
+    return 0;
 }
 
 }  // extern "C"

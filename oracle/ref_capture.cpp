@@ -64,6 +64,13 @@
 #include "volumes/homogeneous.h"
 #include "volumes/rainbow.h"
 #include "volumes/volumegrid.h"
+#include "camera.h"
+#include "film.h"
+#include "filter.h"
+#include "cameras/perspective.h"
+#include "film/image.h"
+#include "filters/gaussian.h"
+#include "samplers/lowdiscrepancy.h"
 #undef private
 #undef protected
 
@@ -614,6 +621,163 @@ static int cmdLi(const std::string &name, const char *photonPath, const char *ra
     return out.save(outPath) ? 0 : 1;
 }
 
+// The caller and the consumer of Li(): LDSampler, PerspectiveCamera, ImageFilm, made by the reference's own
+// Create*() functions.  SamplerRendererTask itself cannot be linked (it is a Task: core/parallel.cpp), so the
+// sample loop of SamplerRendererTask::Run (samplerrenderer.cpp:85-146) is walked here in the same order with
+// the reference's objects; the surface term of SamplerRenderer::Li is left out (Ls = Lvi), as in include/pvol.h.
+static int cmdRender(const std::string &name, const char *photonPath, const char *outPath, int argc, char **argv) {
+    BuiltScene B;
+    memset(&B.nx, 0, sizeof(int) * 3);
+    if (!buildByName(B, name)) return 1;
+    int xres = 32, yres = 18, spp = 4, nTasks = 8;
+    std::vector<uint32_t> tasks;
+    for (int i = 0; i + 1 < argc; i += 2) {
+        if (!strcmp(argv[i], "stepsize")) B.stepSize = (float)atof(argv[i + 1]);
+        else if (!strcmp(argv[i], "nused")) B.nUsed = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "maxdist")) B.maxDist = (float)atof(argv[i + 1]);
+        else if (!strcmp(argv[i], "xres")) xres = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "yres")) yres = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "spp")) spp = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "ntasks")) nTasks = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "tasks")) {
+            const char *q = argv[i + 1];
+            while (*q) { tasks.push_back((uint32_t)strtoul(q, (char **)&q, 10)); if (*q == ',') ++q; }
+        }
+    }
+    if (tasks.empty()) for (int t = 0; t < nTasks; ++t) tasks.push_back(t);
+    ParamSet surfp, volp;
+    PhotonShooter *psh = CreatePhotonShooter(surfp, volp);
+    Blob pb;
+    if (strcmp(photonPath, "-")) {
+        if (!pb.load(photonPath)) { fprintf(stderr, "cannot read %s\n", photonPath); return 1; }
+        size_t m = pb.get("p").count() / 3;
+        const float *pp = pb.get("p").f32(), *pw = pb.get("wi").f32(), *pa = pb.get("alpha").f32();
+        vector<Photon> photons;
+        for (size_t i = 0; i < m; ++i)
+            photons.push_back(Photon(Point(pp[3 * i], pp[3 * i + 1], pp[3 * i + 2]), specFrom(pa + 30 * i), Vector(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2])));
+        if (m) psh->volumeMap = new KdTree<Photon>(photons);
+    }
+    ParamSet vp;
+    vp.AddFloat("stepsize", &B.stepSize, 1);
+    vp.AddInt("nused", &B.nUsed, 1);
+    vp.AddFloat("maxdist", &B.maxDist, 1);
+    PhotonVolumeIntegrator *vi = CreatePhotonVolumeIntegrator(vp, psh);
+    CaptureRenderer renderer(vi);
+
+    // Film "image" + PixelFilter "gaussian" (defaults), Camera "perspective", Sampler "lowdiscrepancy": core/api.cpp:1221-1288
+    ParamSet filtp, filmp, camp, sampp;
+    Filter *filter = CreateGaussianFilter(filtp);
+    std::string fname = "ref_capture_unused.tga";
+    filmp.AddInt("xresolution", &xres, 1);
+    filmp.AddInt("yresolution", &yres, 1);
+    filmp.AddString("filename", &fname, 1);
+    ImageFilm *film = CreateImageFilm(filmp, filter);
+    camp.AddFloat("fov", &B.fov, 1);
+    Transform *c2w = keep(B.camToWorld);
+    AnimatedTransform ac2w(c2w, 0.f, c2w, 1.f);
+    PerspectiveCamera *camera = CreatePerspectiveCamera(camp, ac2w, film);
+    sampp.AddInt("pixelsamples", &spp, 1);
+    LDSampler *mainSampler = CreateLowDiscrepancySampler(sampp, film, camera);
+    Sample *origSample = new Sample(mainSampler, NULL, vi, B.scene);
+
+    Blob out;
+    std::vector<float> r2c, c2wm, ftab(film->filterTable, film->filterTable + 256);
+    putMat(r2c, camera->RasterToCamera.m);
+    putMat(c2wm, camera->CameraToWorld.startTransform->m);
+    out.putf("camera.raster_to_camera", r2c);
+    out.putf("camera.camera_to_world", c2wm);
+    float shutter[4] = {camera->shutterOpen, camera->shutterClose, camera->lensRadius, camera->focalDistance};
+    out.putf("camera.shutter_lens", shutter, 4);
+    out.putf("film.filter_table", ftab);
+    float fw[2] = {filter->xWidth, filter->yWidth};
+    out.putf("film.filter_width", fw, 2);
+    int32_t ext[4];
+    film->GetSampleExtent(&ext[0], &ext[1], &ext[2], &ext[3]);
+    out.put("sampler.extent", blob::I32, ext, 4);
+    int32_t si[6] = {xres, yres, mainSampler->samplesPerPixel, nTasks, (int32_t)vi->tauSampleOffset, (int32_t)vi->scatterSampleOffset};
+    out.put("sampler.i", blob::I32, si, 6);
+    std::vector<uint32_t> n1d(origSample->n1D.begin(), origSample->n1D.end()), n2d(origSample->n2D.begin(), origSample->n2D.end());
+    out.putu("sampler.n1d", n1d);
+    out.putu("sampler.n2d", n2d);
+    out.putu("tasks", tasks);
+
+    std::vector<float> sImg, sTime, sLens, sTau, sScat, rayO, rayD, rayT, xyzT;
+    std::vector<uint32_t> skip, nextRng, nSamples;
+    std::vector<int32_t> windows;
+    std::vector<uint64_t> endDraws;
+    MemoryArena arena;
+    for (size_t ti = 0; ti < tasks.size(); ++ti) {
+        int taskNum = (int)tasks[ti];
+        int w[4] = {0, 0, 0, 0};
+        mainSampler->ComputeSubWindow(taskNum, nTasks, &w[0], &w[1], &w[2], &w[3]);
+        for (int k = 0; k < 4; ++k) windows.push_back(w[k]);
+        Sampler *sampler = mainSampler->GetSubSampler(taskNum, nTasks);
+        if (!sampler) { endDraws.push_back(0); nextRng.push_back(0); nSamples.push_back(0); continue; }
+        RNG rng(taskNum), shadow(taskNum);
+        uint64_t total = 0;
+        uint32_t count = 0;
+        int maxSamples = sampler->MaximumSampleCount();
+        Sample *samples = origSample->Duplicate(maxSamples);
+        std::vector<Spectrum> LsAll(maxSamples);
+        int sampleCount;
+        while ((sampleCount = sampler->GetMoreSamples(samples, rng)) > 0) {
+            uint64_t ds = drawsBetween(shadow, rng, 100000000);
+            total += ds;
+            for (int i = 0; i < sampleCount; ++i) {
+                RayDifferential ray;
+                float rayWeight = camera->GenerateRayDifferential(samples[i], &ray);
+                ray.ScaleDifferentials(1.f / sqrtf(sampler->samplesPerPixel));
+                Intersection isect;
+                B.scene->Intersect(ray, &isect);                      // SamplerRenderer::Li, samplerrenderer.cpp:236-249
+                Spectrum T(1.f);
+                Spectrum Ls = rayWeight * vi->Li(B.scene, &renderer, ray, &samples[i], rng, &T, arena);
+                if (Ls.HasNaNs() || Ls.y() < -1e-5 || isinf(Ls.y())) Ls = Spectrum(0.f);
+                uint64_t d = drawsBetween(shadow, rng, 100000000);
+                total += d;
+                LsAll[i] = Ls;
+                float xyz[3];
+                Ls.ToXYZ(xyz);
+                sImg.push_back(samples[i].imageX); sImg.push_back(samples[i].imageY);
+                sTime.push_back(samples[i].time);
+                sLens.push_back(samples[i].lensU); sLens.push_back(samples[i].lensV);
+                sTau.push_back(samples[i].oneD[vi->tauSampleOffset][0]);
+                sScat.push_back(samples[i].oneD[vi->scatterSampleOffset][0]);
+                rayO.push_back(ray.o.x); rayO.push_back(ray.o.y); rayO.push_back(ray.o.z);
+                rayD.push_back(ray.d.x); rayD.push_back(ray.d.y); rayD.push_back(ray.d.z);
+                rayT.push_back(ray.mint); rayT.push_back(ray.maxt);
+                xyzT.push_back(xyz[0]); xyzT.push_back(xyz[1]); xyzT.push_back(xyz[2]); xyzT.push_back(T.y());
+                skip.push_back(i == 0 ? (uint32_t)ds : 0u);
+                ++count;
+            }
+            if (sampler->ReportResults(samples, NULL, NULL, NULL, sampleCount))   // samplerrenderer.cpp:137-146
+                for (int i = 0; i < sampleCount; ++i) film->AddSample(samples[i], LsAll[i]);
+            arena.FreeAll();
+        }
+        endDraws.push_back(total);
+        nextRng.push_back(rng.RandomUInt());
+        nSamples.push_back(count);
+        delete sampler;
+    }
+    out.putf("samples.image", sImg); out.putf("samples.time", sTime); out.putf("samples.lens", sLens);
+    out.putf("samples.tau", sTau); out.putf("samples.scatter", sScat);
+    out.putf("rays.o", rayO); out.putf("rays.d", rayD); out.putf("rays.t", rayT); out.putf("xyzT", xyzT);
+    out.putu("rays.skip", skip); out.putu("next_rng", nextRng); out.putu("task.n_samples", nSamples);
+    out.put("task.window", blob::I32, windows.data(), windows.size());
+    out.put("task.end_draw", blob::U64, endDraws.data(), endDraws.size());
+    std::vector<float> pix;
+    for (int y = 0; y < yres; ++y)
+        for (int x = 0; x < xres; ++x) {
+            const ImageFilm::Pixel &px = (*film->pixels)(x, y);
+            pix.push_back(px.Lxyz[0]); pix.push_back(px.Lxyz[1]); pix.push_back(px.Lxyz[2]); pix.push_back(px.weightSum);
+        }
+    out.putf("film.pixels", pix);
+    float *rgb = NULL;
+    int fwid = 0, fhei = 0;
+    film->WriteRGB(&rgb, &fwid, &fhei, 1.f);
+    out.putf("film.rgb", rgb, (size_t)3 * fwid * fhei);
+    return out.save(outPath) ? 0 : 1;
+}
+
 // Building blocks of the photon shooter, evaluated by the reference's objects.
 static int cmdUnits(const std::string &name, const char *outPath) {
     BuiltScene B;
@@ -750,6 +914,7 @@ int main(int argc, char **argv) {
     if (argc >= 3 && !strcmp(argv[1], "tables")) return cmdTables(argv[2]);
     if (argc >= 4 && !strcmp(argv[1], "scene")) return cmdScene(argv[2], argv[3]);
     if (argc >= 4 && !strcmp(argv[1], "units")) return cmdUnits(argv[2], argv[3]);
+    if (argc >= 5 && !strcmp(argv[1], "render")) return cmdRender(argv[2], argv[3], argv[4], argc - 5, argv + 5);
     if (argc >= 6 && !strcmp(argv[1], "li")) return cmdLi(argv[2], argv[3], argv[4], argv[5], argc - 6, argv + 6);
     fprintf(stderr,
             "usage: ref_capture tables OUT | scene NAME OUT | units NAME OUT | li NAME PHOTONS|- RAYS OUT [stepsize v] [nused v] [maxdist v]\n");

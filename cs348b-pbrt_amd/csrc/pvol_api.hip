@@ -120,6 +120,7 @@ void pvol_destroy(pvol_ctx *c) {
     if (c->dDensity) hipFree(c->dDensity);
     if (c->dRecords) hipFree(c->dRecords);
     if (c->dState) hipFree(c->dState);
+    for (int i = 0; i < 6; ++i) if (c->dTile[i]) hipFree(c->dTile[i]);
     if (c->ds) hipFree(c->ds);
     if (c->dsh) hipFree(c->dsh);
     if (c->dCounters) hipFree(c->dCounters);
@@ -381,6 +382,22 @@ static bool par_eligible(const pvol_ctx *c) { return c->hs.nLights <= 1 && c->hs
 static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
                   float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, uint32_t maxRaysPerStream,
                   hipStream_t stream) {
+    return pvol_launch_batch(c, dRays, nRays, dStreams, nStreams, outputKind, dOut, dDraws, dInit, dFinal, transOnly, maxRaysPerStream, 0, stream);
+}
+
+// Whether a single march step can reach the Russian roulette (Tr.y() < 1e-3, photonvolume.cpp:156-161): Tr is
+// ASSIGNED per step, a step is at most stepSize long, so exp(-stepSize * max sigma_t) bounds it from below.
+static bool roulette_possible(const pvol_ctx *c) {
+    float m = 0.f;
+    for (int i = 0; i < PVOL_NBINS; ++i) m = std::max(m, c->hs.sigA[i] + c->hs.sigS[i]);
+    return !(c->hs.stepSize * m < 6.8f);
+}
+
+// `tile` != 0: the rays do not exist yet -- the tile kernel (pvol_tile_dev.h) generates them stream by stream
+// (LD sampler + camera) in front of the march, and takes the place of the RESOLVE pre-pass where one is needed.
+int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
+                      float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, uint32_t maxRaysPerStream,
+                      const TileArgs *tile, hipStream_t stream) {
     LiArgs a;
     memset(&a, 0, sizeof(a));
     a.scene = c->ds; a.rays = dRays; a.streams = dStreams; a.nStreams = nStreams; a.nRays = nRays; a.outputKind = outputKind;
@@ -394,9 +411,13 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
         else if (!ok(hipEventCreate(&ev.first)) || !ok(hipEventCreate(&ev.second))) return PVOL_E_NO_DEVICE;
     }
     hipError_t e;
-    const bool par = par_eligible(c) && !dInit && !c->forceSeq;
+    // the tile pre-pass can COUNT Li()'s draws (instead of drawing them) under the same conditions as li_par_kernel,
+    // provided no march step can reach the roulette
+    const bool tileCount = tile && par_eligible(c) && !dInit && !roulette_possible(c);
+    const bool par = par_eligible(c) && !dInit && !c->forceSeq && (!tile || tileCount);
     // scenes where drawn values matter: sequential RESOLVE pre-pass + ray-parallel REPLAY, slice by slice
-    const bool sliced = !par && !c->forceSeq && !transOnly && c->hs.volKind != PVOL_VOLUME_NONE;
+    const bool sliced = !par && !c->forceSeq && !transOnly && (c->hs.volKind != PVOL_VOLUME_NONE || tile);
+    if (tile && !par && !sliced && !tileCount) return PVOL_E_UNSUPPORTED;
     uint32_t sliceM = 0, nSlices = 0;
     if (sliced) {
         uint32_t maxRays = maxRaysPerStream;
@@ -413,6 +434,10 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
         m = std::max<size_t>(64, std::min<size_t>(m, ((size_t)maxRays + 63) & ~(size_t)63));
         m &= ~(size_t)63;
         if (const char *ev = getenv("PVOL_SLICE_RAYS")) { long v = atol(ev); if (v >= 64) m = (size_t)v & ~(size_t)63; }   // testing: force many slices
+        if (tile) {   // a slice holds whole pixels (both powers of two)
+            const size_t unit = std::max<size_t>(64, tile->spp);
+            m = std::max(unit, m / unit * unit);
+        }
         sliceM = (uint32_t)m;
         nSlices = maxRays ? (maxRays + sliceM - 1) / sliceM : 1;
         size_t recBytes = stride * (size_t)nStreams * sliceM, stBytes = sizeof(uint32_t) * 625 * (size_t)nStreams;
@@ -423,11 +448,16 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
         a.records = c->dRecords; a.recStride = (uint32_t)stride; a.sliceM = sliceM; a.state = c->dState;
     }
     if (par) hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
+    if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel
+        a.sliceK = 0; a.sliceM = 0xffffffc0u; a.state = 0;
+        if (!ok(pvol_launch_tile(&a, tile, false, pvol_tile_lds_bytes(0, tile->spp, false), c->hs.candCap, stream))) return PVOL_E_NO_DEVICE;
+    }
     hipEventRecord(ev.first, stream);
     if (par) {
         unsigned long long chunks = ((unsigned long long)nRays + 63ull) / 64ull;
         uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
-        e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
+        e = hipSuccess;
+        if (ok(e)) e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
         if (ok(e)) {   // runs only if a ray raised needSeq (gate read on the device: no host sync here)
             a.gated = 1;
             e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
@@ -439,7 +469,9 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
         for (uint32_t k = 0; k < nSlices && ok(e); ++k) {
             a.sliceK = k;
             hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
-            e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
+            if (tile) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true), c->hs.candCap, stream);
+            if (ok(e)) e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream,
+                                                tile == 0);
         }
     } else {
         e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);

@@ -96,4 +96,17 @@ struct DevCounters {
     unsigned long long cySearch, cySelect, cyFlux, cyTotal;  // s_memtime cycles summed over waves (stats build only)
 };
 
+// Tile driver (pvol_tile_dev.h, pvol_tile.hip): what a SamplerRendererTask needs besides the scene.
+struct TileArgs {
+    float r2c[16], c2w[16];        // PerspectiveCamera::RasterToCamera, Camera::CameraToWorld
+    float shutterOpen, shutterClose;
+    uint32_t spp;                  // LDSampler::nPixelSamples
+    uint32_t n1dCount, n2dCount;
+    uint32_t n1d[PVOL_MAX_SAMPLE_ARRAYS], n2d[PVOL_MAX_SAMPLE_ARRAYS];
+    uint32_t scatterIndex;
+    const int4 *windows;           // per stream of the batch: x0, x1, y0, y1 (Sampler::ComputeSubWindow)
+    pvol_ray *rays;                // out: camera rays, stream-major, pixel-major, sample-minor
+    float *xy;                     // out: imageX, imageY per ray
+};
+
 #endif

@@ -39,7 +39,9 @@ struct GridBuildArgs {
 };
 extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
-                                           uint32_t nWaves, hipStream_t stream);
+                                           uint32_t nWaves, hipStream_t stream, bool resolve);
+extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused);
+extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
                                       uint32_t *cellStart, hipStream_t stream);
@@ -75,8 +77,16 @@ struct pvol_ctx {
     DevShootScene hsh;
     DevShootScene *dsh;
     uint64_t shootStats[12];
+    // tile driver work buffers (grown on demand, pvol_tile.hip)
+    void *dTile[6] = {0, 0, 0, 0, 0, 0};
+    size_t tileBytes[6] = {0, 0, 0, 0, 0, 0};
 };
 
+
+struct pvol_ctx;
+extern "C" int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
+                      float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, uint32_t maxRaysPerStream,
+                      const TileArgs *tile, hipStream_t stream);
 
 extern "C" {
 // finish a photon map whose raw arrays (dRawP/dRawWi/dRawAlpha, n photons) are already on the device

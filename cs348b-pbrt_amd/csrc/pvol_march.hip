@@ -1217,16 +1217,18 @@ extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, in
 
 // one slice: resolve (wave per stream) then replay (wave per ray); chunkCounter must be zero before the replay
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
-                                           uint32_t nWaves, hipStream_t stream) {
+                                           uint32_t nWaves, hipStream_t stream, bool resolve) {
     dim3 block(LANES);
     if (candCap <= 4 * LANES) {
-        hipLaunchKernelGGL((li_resolve_kernel<false, 4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+        if (resolve) hipLaunchKernelGGL((li_resolve_kernel<false, 4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
         if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 4>), dim3(nWaves), block, ldsReplay, stream, *args);
         else hipLaunchKernelGGL((li_replay_kernel<false, 4>), dim3(nWaves), block, ldsReplay, stream, *args);
     } else {
-        hipLaunchKernelGGL((li_resolve_kernel<false, 12>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+        if (resolve) hipLaunchKernelGGL((li_resolve_kernel<false, 12>), dim3(args->nStreams), block, ldsResolve, stream, *args);
         if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 12>), dim3(nWaves), block, ldsReplay, stream, *args);
         else hipLaunchKernelGGL((li_replay_kernel<false, 12>), dim3(nWaves), block, ldsReplay, stream, *args);
     }
     return hipGetLastError();
 }
+
+#include "pvol_tile_dev.h"

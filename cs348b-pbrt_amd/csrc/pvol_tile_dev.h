@@ -1,0 +1,293 @@
+// pvol_tile_dev.h -- included at the end of pvol_march.hip (needs march_ray<MODE_RESOLVE> and the LDS MT19937).
+// The sequential half of a SamplerRendererTask (renderers/samplerrenderer.cpp:59-157): one wave per render
+// task walks the task's pixels in LDSampler order (samplers/lowdiscrepancy.cpp:69-80), draws LDPixelSample
+// (core/montecarlo.cpp:200-254) from the task's MT19937 stream, turns the samples into camera rays
+// (cameras/perspective.cpp:80-134), clips them at the closest surface (Scene::Intersect) and finds out how many
+// draws each Li() call will make, because the NEXT pixel's samples depend on where the stream then stands:
+//   COUNT  (scenes where no drawn value reaches Li's result and the roulette cannot fire): one camera sample per
+//          lane counts 4 + 6n + n + u; the heavy kernel is li_par_kernel
+//   FUSED  (everything else): every ray is walked by march_ray<MODE_RESOLVE>, which draws for real and leaves the
+//          per-step records li_replay_kernel reads -- this kernel then stands in for li_resolve_kernel
+// The rays it writes carry rng_skip = the sampler's draws in front of the pixel's first sample, so the batch is
+// also a valid input of every other Li kernel.
+
+// draw j of the next `cnt` (<= 64) draws lands in lane j; the stream advances by cnt
+__device__ __forceinline__ uint32_t rng_bulk(Rng &r, int cnt, int lane) {
+    uint32_t out = 0u;
+    int done = 0;
+    r.draws += (unsigned long long)cnt;
+    while (done < cnt) {
+        if (r.mti >= MT_N) { mt_regenerate(r.mt, lane); r.mti = 0; }
+        const int take = min(cnt - done, MT_N - r.mti);
+        if (lane >= done && lane < done + take) {
+            uint32_t y = r.mt[r.mti + lane - done];
+            y ^= (y >> 11);
+            y ^= (y << 7) & 0x9d2c5680u;
+            y ^= (y << 15) & 0xefc60000u;
+            y ^= (y >> 18);
+            out = y;
+        }
+        r.mti += take;
+        done += take;
+    }
+    return out;
+}
+
+// core/montecarlo.h:289-293
+__device__ __forceinline__ float sobol2(uint32_t n, uint32_t scramble) {
+    for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)
+        if (n & 0x1) scramble ^= v;
+    return fminf(((scramble >> 8) & 0xffffff) / float(1 << 24), 0x1.fffffep-1f);
+}
+
+// Shuffle(samp, count, dims, rng), core/montecarlo.h:174-181: the `other` indices are drawn 64 at a time, the
+// swaps themselves are order-dependent and run on lane 0
+__device__ void tile_shuffle(float *samp, uint32_t count, uint32_t dims, uint32_t *oth, Rng &rng, int lane) {
+    for (uint32_t base = 0; base < count; base += LANES) {
+        const int cnt = (int)min((uint32_t)LANES, count - base);
+        const uint32_t r = rng_bulk(rng, cnt, lane);
+        const uint32_t i = base + (uint32_t)lane;
+        if (lane < cnt) oth[i] = i + (r % (count - i));
+    }
+    __syncthreads();
+    if (lane == 0) {
+        for (uint32_t i = 0; i < count; ++i) {
+            const uint32_t o = oth[i];
+            for (uint32_t j = 0; j < dims; ++j) {
+                float a = samp[dims * i + j], b = samp[dims * o + j];
+                samp[dims * i + j] = b;
+                samp[dims * o + j] = a;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+struct TileLds {
+    float *image;    // 2 * spp
+    float *time;     // spp
+    float *scatter;  // spp
+    uint32_t *oth;   // spp
+};
+
+// LDPixelSample, core/montecarlo.cpp:200-254.  Arrays nobody on this path reads (lens, tau and other
+// integrators' requests) only advance the stream by what generating them draws.
+__device__ void tile_pixel_sample(const TileArgs &T, TileLds &L, Rng &rng, int lane) {
+    const uint32_t n = T.spp;
+    // image: LDShuffleScrambled2D(1, n): 2 scrambles, n no-op Shuffles of one element (one draw each), Shuffle(n, 2)
+    {
+        const uint32_t s0 = rng_uint<true>(rng, lane), s1 = rng_uint<true>(rng, lane);
+        for (uint32_t i = lane; i < n; i += LANES) { L.image[2 * i] = van_der_corput(i, s0); L.image[2 * i + 1] = sobol2(i, s1); }
+        rng_skip<true>(rng, n, lane);
+        __syncthreads();
+        tile_shuffle(L.image, n, 2, L.oth, rng, lane);
+    }
+    rng_skip<true>(rng, 2ull + 2ull * n, lane);   // lens
+    {
+        const uint32_t s = rng_uint<true>(rng, lane);
+        for (uint32_t i = lane; i < n; i += LANES) L.time[i] = van_der_corput(i, s);
+        rng_skip<true>(rng, n, lane);
+        __syncthreads();
+        tile_shuffle(L.time, n, 1, L.oth, rng, lane);
+    }
+    for (uint32_t a = 0; a < T.n1dCount; ++a) {
+        if (a == T.scatterIndex) {   // n1d == 1 (checked on the host)
+            const uint32_t s = rng_uint<true>(rng, lane);
+            for (uint32_t i = lane; i < n; i += LANES) L.scatter[i] = van_der_corput(i, s);
+            rng_skip<true>(rng, n, lane);
+            __syncthreads();
+            tile_shuffle(L.scatter, n, 1, L.oth, rng, lane);
+        } else {
+            rng_skip<true>(rng, 1ull + (unsigned long long)T.n1d[a] * n + n, lane);
+        }
+    }
+    for (uint32_t a = 0; a < T.n2dCount; ++a) rng_skip<true>(rng, 2ull + (unsigned long long)T.n2d[a] * n + n, lane);
+}
+
+// PerspectiveCamera::GenerateRayDifferential without a lens + CameraToWorld (static transform)
+__device__ __forceinline__ void tile_camera_ray(const TileArgs &T, float imageX, float imageY, V3 *o, V3 *d) {
+    const float *m = T.r2c;
+    V3 pc;
+    pc.x = m[0] * imageX + m[1] * imageY + m[2] * 0.f + m[3];
+    pc.y = m[4] * imageX + m[5] * imageY + m[6] * 0.f + m[7];
+    pc.z = m[8] * imageX + m[9] * imageY + m[10] * 0.f + m[11];
+    const float w = m[12] * imageX + m[13] * imageY + m[14] * 0.f + m[15];
+    if (w != 1.f) { const float inv = 1.f / w; pc.x *= inv; pc.y *= inv; pc.z *= inv; }
+    const V3 dir = normalize(pc);
+    const float *c = T.c2w;
+    V3 ow = v3(c[0] * 0.f + c[1] * 0.f + c[2] * 0.f + c[3], c[4] * 0.f + c[5] * 0.f + c[6] * 0.f + c[7],
+               c[8] * 0.f + c[9] * 0.f + c[10] * 0.f + c[11]);
+    const float ww = c[12] * 0.f + c[13] * 0.f + c[14] * 0.f + c[15];
+    if (ww != 1.f) { const float inv = 1.f / ww; ow.x *= inv; ow.y *= inv; ow.z *= inv; }
+    *o = ow;
+    *d = xform_vector(c, dir);
+}
+
+// Scene::Intersect as SamplerRenderer::Li uses it (samplerrenderer.cpp:236-249): only the clipped maxt matters here
+__device__ __forceinline__ float tile_clip(const DevScene &S, V3 o, V3 d) {
+    float mt = INFINITY;
+    for (int i = 0; i < S.nTris; ++i) {
+        float t;
+        if (tri_closest(S.tris[i], o, d, 0.f, mt, &t)) mt = t;
+    }
+    return mt;
+}
+
+// Number of RandomUInt calls of one Li() when no roulette can fire and at most one light exists: 4 + 6n + n + u
+// (photonvolume.cpp:112-222; same per-step tests as march_ray_blocked's scalar phase).  One ray per lane.
+__device__ uint32_t tile_count_draws(const DevScene &S, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack) {
+    RayD ray;
+    ray.o = o; ray.d = d; ray.mint = 0.f; ray.maxt = maxt;
+    float t0, t1;
+    if (S.volKind == PVOL_VOLUME_NONE || !vol_intersect(S, ray, &t0, &t1) || (t1 - t0) == 0.f) return 0u;
+    const int nSamples = (int)ceilf((t1 - t0) / S.stepSize);
+    const float step = (t1 - t0) / nSamples;
+    float tcur = t0 + scatterU * step;
+    uint32_t u = 0;
+    const bool tryLight = !blackS && S.nLights > 0 && !lightBlack;
+    for (int j = 0; j < nSamples; ++j) {
+        const V3 p = o + d * tcur;
+        tcur += step;
+        if (!tryLight) continue;
+        if (!box_inside(S.extLo, S.extHi, xform_point(S.w2v, p))) continue;
+        const DevLight &light = S.lights[0];
+        RayD vis;
+        if (light.kind == PVOL_LIGHT_DISTANT) {
+            vis.o = p; vis.d = v3(light.dir[0], light.dir[1], light.dir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
+        } else {
+            const V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
+            const V3 wo = normalize(lp - p);
+            const float dist = len(p - lp);
+            vis.o = p; vis.d = vdiv(lp - p, dist); vis.mint = 0.f; vis.maxt = dist * (1.f - 0.f);
+            if (light.kind == PVOL_LIGHT_SPOT) {
+                V3 wl = normalize(v3(light.w2l[0] * -wo.x + light.w2l[1] * -wo.y + light.w2l[2] * -wo.z,
+                                     light.w2l[4] * -wo.x + light.w2l[5] * -wo.y + light.w2l[6] * -wo.z,
+                                     light.w2l[8] * -wo.x + light.w2l[9] * -wo.y + light.w2l[10] * -wo.z));
+                const float costheta = wl.z;   // SpotLight::Falloff, spot.cpp:60-69; 0 means L.IsBlack()
+                float fall = 1.f;
+                if (costheta < light.cosTotalWidth) fall = 0.f;
+                else if (!(costheta > light.cosFalloffStart)) {
+                    const float delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+                    fall = delta * delta * delta * delta;
+                }
+                if (fall == 0.f) continue;
+            }
+        }
+        if (!lane_occluded(S, vis)) ++u;
+    }
+    return 4u + 7u * (uint32_t)nSamples + u;
+}
+
+template <bool FUSED, int NREG>
+__global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    const uint32_t sidx = blockIdx.x;
+    if (sidx >= A.nStreams) return;
+    uint32_t *mt = reinterpret_cast<uint32_t *>(lds);
+    MarchLds M;
+    M.G.cap = 0; M.G.cd = 0; M.G.ci = 0; M.G.paint = 0;
+    M.lightNum = reinterpret_cast<float *>(lds + MT_N * 4);
+    M.prevRk = 0;
+    TileLds L;
+    L.image = M.lightNum + (FUSED ? S.maxSteps : 0);
+    L.time = L.image + 2 * T.spp;
+    L.scatter = L.time + T.spp;
+    L.oth = reinterpret_cast<uint32_t *>(L.scatter + T.spp);
+    const pvol_stream st = A.streams[sidx];
+    const uint32_t begin = A.sliceK * A.sliceM;
+    if (begin >= st.n_rays && !(A.sliceK == 0)) return;
+    Rng rng;
+    rng.mt = mt;
+    rng.draws = 0;
+    uint32_t *state = A.state ? A.state + (size_t)sidx * (MT_N + 1) : 0;
+    if (A.sliceK == 0) {
+        mt_seed(mt, st.seed, lane);
+        rng.mti = MT_N;
+        rng_skip<true>(rng, st.start_draw, lane);
+    } else {
+        for (int i = lane; i < MT_N; i += LANES) mt[i] = state[i];
+        rng.mti = (int)state[MT_N];
+        rng.draws = st.end_draw;
+        __syncthreads();
+    }
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    const bool grid = (S.volKind == PVOL_VOLUME_GRID);
+    const uint32_t end = min(st.n_rays, begin + A.sliceM);
+    const int4 w = T.windows[sidx];
+    const uint32_t width = (uint32_t)(w.y - w.x);
+    const int q = lane & 7;
+    const bool blackS = spec_is_black(ld4(S.sigS, q));
+    const bool lightBlack = S.nLights > 0 ? spec_is_black(ld4(S.lights[0].intensity, q)) : true;
+    pvol_ray *rays = T.rays;
+    for (uint32_t k = begin; k < end; k += T.spp) {
+        const uint32_t pix = k / T.spp;
+        const int xPos = w.x + (int)(pix % width), yPos = w.z + (int)(pix / width);
+        const unsigned long long d0 = rng.draws;
+        tile_pixel_sample(T, L, rng, lane);
+        const uint32_t samplerDraws = (uint32_t)(rng.draws - d0);
+        for (uint32_t s0 = 0; s0 < T.spp; s0 += LANES) {
+            const uint32_t i = s0 + (uint32_t)lane;
+            const bool on = i < T.spp;
+            const int cnt = (int)min((uint32_t)LANES, T.spp - s0);
+            float imageX = 0.f, imageY = 0.f, tm = 0.f, su = 0.f, maxt = INFINITY;
+            V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
+            const size_t ri = (size_t)st.first_ray + k + i;
+            if (on) {
+                imageX = xPos + L.image[2 * i];
+                imageY = yPos + L.image[2 * i + 1];
+                tm = lerpf(L.time[i], T.shutterOpen, T.shutterClose);
+                su = L.scatter[i];
+                tile_camera_ray(T, imageX, imageY, &o, &d);
+                maxt = tile_clip(S, o, d);
+                pvol_ray pr;
+                pr.o[0] = o.x; pr.o[1] = o.y; pr.o[2] = o.z; pr.mint = 0.f;
+                pr.d[0] = d.x; pr.d[1] = d.y; pr.d[2] = d.z; pr.maxt = maxt;
+                pr.time = tm; pr.scatter_u = su; pr.rng_skip = (i == 0) ? samplerDraws : 0u; pr.flags = 0u;
+                rays[ri] = pr;
+                T.xy[2 * ri] = imageX;
+                T.xy[2 * ri + 1] = imageY;
+            }
+            if (!FUSED) {
+                uint32_t nd = on ? tile_count_draws(S, o, d, maxt, su, blackS, lightBlack) : 0u;
+                // wave total (integer adds in any order are exact)
+                unsigned long long tot = nd;
+                for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+                rng_skip<true>(rng, tot, lane);
+            } else {
+                for (int j = 0; j < cnt; ++j) {
+                    pvol_ray pr;
+                    pr.o[0] = lane_f(o.x, j); pr.o[1] = lane_f(o.y, j); pr.o[2] = lane_f(o.z, j); pr.mint = 0.f;
+                    pr.d[0] = lane_f(d.x, j); pr.d[1] = lane_f(d.y, j); pr.d[2] = lane_f(d.z, j); pr.maxt = lane_f(maxt, j);
+                    pr.time = lane_f(tm, j); pr.scatter_u = lane_f(su, j); pr.rng_skip = 0u; pr.flags = 0u;
+                    const unsigned long long r0 = rng.draws;
+                    const size_t rj = (size_t)st.first_ray + k + s0 + (uint32_t)j;
+                    RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k + s0 + (uint32_t)j - begin)) * A.recStride, S.maxSteps, grid);
+                    f4 Lv, Tr;
+                    march_ray<false, MODE_RESOLVE, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
+                    if (lane == 0) rec.hdr[2] = (uint32_t)(rng.draws - r0);
+                    if (A.draws && lane == 0) A.draws[rj] = (uint32_t)(rng.draws - r0);
+                }
+            }
+        }
+    }
+    if (lane == 0) A.streams[sidx].end_draw = rng.draws;
+    if (state) {
+        __syncthreads();
+        for (int i = lane; i < MT_N; i += LANES) state[i] = mt[i];
+        if (lane == 0) state[MT_N] = (uint32_t)rng.mti;
+    }
+}
+
+extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused) {
+    return (size_t)MT_N * 4 + (fused ? (size_t)maxSteps * 4 : 0) + (size_t)spp * 5 * 4;
+}
+
+extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream) {
+    dim3 grid(args->nStreams), block(LANES);
+    if (!fused) hipLaunchKernelGGL((tile_kernel<false, 4>), grid, block, ldsBytes, stream, *args, *tile);
+    else if (candCap <= 4 * LANES) hipLaunchKernelGGL((tile_kernel<true, 4>), grid, block, ldsBytes, stream, *args, *tile);
+    else hipLaunchKernelGGL((tile_kernel<true, 12>), grid, block, ldsBytes, stream, *args, *tile);
+    return hipGetLastError();
+}

@@ -57,6 +57,16 @@ def lib():
         L.pvol_enable_stats.argtypes = [C.c_void_p, C.c_int]
         L.pvol_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.pvol_get_shoot_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.pvol_gaussian_filter_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
+        L.pvol_gaussian_filter_table.restype = None
+        L.pvol_compute_sub_window.argtypes = [C.POINTER(abi.Sampler), C.c_uint32, C.POINTER(C.c_int32)]
+        L.pvol_compute_sub_window.restype = None
+        L.pvol_render_sample_count.argtypes = [C.POINTER(abi.Sampler), _u32p, C.c_uint32]
+        L.pvol_render_sample_count.restype = C.c_uint64
+        L.pvol_render_tasks_device.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Film), C.POINTER(abi.Sampler), _u32p, C.c_uint32,
+                                               C.c_void_p, C.POINTER(abi.RenderDebug), C.c_void_p]
+        L.pvol_film_add_samples_device.argtypes = [C.c_void_p, C.POINTER(abi.Film), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
+        L.pvol_film_resolve_device.argtypes = [C.c_void_p, C.POINTER(abi.Film), C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -64,7 +74,9 @@ def lib():
 EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_default_params", "pvol_create",
            "pvol_destroy", "pvol_set_scene", "pvol_upload_photons", "pvol_preprocess", "pvol_photon_count",
            "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
-           "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats"]
+           "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats",
+           "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
+           "pvol_film_add_samples_device", "pvol_film_resolve_device"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -149,6 +161,19 @@ class PhotonVolume:
         _check(lib().pvol_li_batch_device(self._h, d_rays, n_rays, d_streams, n_streams, output_kind, d_out, d_draws, hip_stream),
                "pvol_li_batch_device")
 
+    # ---- tile driver (device pointers are integers, e.g. torch.Tensor.data_ptr())
+    def render_tasks(self, camera, film, sampler, task_ids, d_pixels, debug=None, hip_stream=0):
+        ids = np.ascontiguousarray(task_ids, np.uint32)
+        _check(lib().pvol_render_tasks_device(self._h, C.byref(camera), C.byref(film), C.byref(sampler), ids.ctypes.data_as(_u32p), len(ids),
+                                              d_pixels, C.byref(debug) if debug is not None else None, hip_stream), "pvol_render_tasks_device")
+
+    def film_add_samples(self, film, d_image_xy, d_xyz, stride, n, d_pixels, hip_stream=0):
+        _check(lib().pvol_film_add_samples_device(self._h, C.byref(film), d_image_xy, d_xyz, stride, n, d_pixels, hip_stream),
+               "pvol_film_add_samples_device")
+
+    def film_resolve(self, film, d_pixels, d_rgb, hip_stream=0):
+        _check(lib().pvol_film_resolve_device(self._h, C.byref(film), d_pixels, d_rgb, hip_stream), "pvol_film_resolve_device")
+
     def li_single(self, ray, mt, mti):
         """Per-sample shim: ray is a length-1 RAY_DTYPE array, mt a uint32[624] array (updated in place)."""
         Lv = np.zeros(30, np.float32)
@@ -181,3 +206,20 @@ class PhotonVolume:
         n = C.c_uint64()
         _check(lib().pvol_kernel_time_ms(self._h, C.byref(avg), C.byref(n), int(reset)), "pvol_kernel_time_ms")
         return avg.value, n.value
+
+
+def gaussian_filter_table(xwidth=2.0, ywidth=2.0, alpha=2.0):
+    t = np.zeros(256, np.float32)
+    lib().pvol_gaussian_filter_table(xwidth, ywidth, alpha, t.ctypes.data_as(_f32p))
+    return t
+
+
+def sub_window(sampler, task):
+    w = (C.c_int32 * 4)()
+    lib().pvol_compute_sub_window(C.byref(sampler), task, w)
+    return list(w)
+
+
+def render_sample_count(sampler, task_ids):
+    ids = np.ascontiguousarray(task_ids, np.uint32)
+    return int(lib().pvol_render_sample_count(C.byref(sampler), ids.ctypes.data_as(_u32p), len(ids)))

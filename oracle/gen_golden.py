@@ -138,6 +138,17 @@ def shoot(scene_name, n_photons, tag, n_tasks=1, **over):
     print("photons_%s: %d photons, %d paths" % (tag, len(P), st["paths"]))
 
 
+def render_case(tag, scene_name, photons, xres, yres, spp, ntasks, tasks=None, **over):
+    """Reference SamplerRendererTask loop (LDSampler + PerspectiveCamera + Li + ImageFilm), ref_capture `render`."""
+    args = ["render", scene_name, os.path.join(GOLD, "photons_%s.bin" % photons) if photons else "-",
+            os.path.join(GOLD, "render_%s.bin" % tag), "xres", xres, "yres", yres, "spp", spp, "ntasks", ntasks]
+    if tasks is not None:
+        args += ["tasks", ",".join(str(t) for t in tasks)]
+    for k, v in over.items():
+        args += [k, v]
+    cap(*args)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     cap("tables", os.path.join(GOLD, "ref_tables.bin"))
@@ -161,6 +172,11 @@ def main():
     # Transmittance() records (sample == NULL path)
     make_case("trans_vh", "volumescene_h", 8, 8, 2, 9, photons=None, transmittance_only=True)
     make_case("trans_grid16", "volumescene_grid16", 8, 8, 2, 10, photons=None, transmittance_only=True)
+    # whole render tasks: sampler + camera + Li + film
+    render_case("vh", "volumescene_h", "vh", 32, 18, 4, 8)
+    render_case("vh64", "volumescene_h", "vh", 10, 6, 64, 4, tasks=[0, 2, 3])
+    render_case("grid16", "volumescene_grid16", "grid16", 16, 10, 2, 4)
+    render_case("pf", "pinkfloyd", "pf", 16, 16, 4, 4, nused=50, maxdist=0.25)
 
 
 if __name__ == "__main__":

@@ -700,6 +700,9 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     out.putu("sampler.n1d", n1d);
     out.putu("sampler.n2d", n2d);
     out.putu("tasks", tasks);
+    float pf[3] = {B.stepSize, B.maxDist, B.shooterStep};
+    out.putf("params.f", pf, 3);
+    out.puti1("params.nused", B.nUsed);
 
     std::vector<float> sImg, sTime, sLens, sTau, sScat, rayO, rayD, rayT, xyzT;
     std::vector<uint32_t> skip, nextRng, nSamples;

@@ -63,6 +63,31 @@ def load_li_case(name):
     return s, p, rays, streams, c
 
 
+# golden whole-task renders (ref_capture `render`): name -> (scene, photon map tag)
+RENDER_CASES = {
+    "vh": ("volumescene_h", "vh"),          # 1 distant light, homogeneous: COUNT pre-pass + li_par_kernel
+    "vh64": ("volumescene_h", "vh"),        # 64 spp: one pixel per wave in the film kernel
+    "grid16": ("volumescene_grid16", "grid16"),   # VolumeGrid: fused RESOLVE pre-pass + replay
+    "pf": ("pinkfloyd", "pf"),              # spot light through a glass prism's triangles
+}
+
+
+def load_render_case(name):
+    """Returns (scene blob, params, camera, film, sampler, case blob) for a golden render case."""
+    c = blob.load(os.path.join(GOLD, "render_%s.bin" % name))
+    s = load_scene(RENDER_CASES[name][0])
+    p = abi.params_from_blob(s, step_size=float(c["params.f"][0]), max_dist=float(c["params.f"][1]),
+                             n_used=int(c["params.nused"][0]))
+    si = c["sampler.i"]
+    cam = abi.make_camera(c["camera.raster_to_camera"], c["camera.camera_to_world"], float(c["camera.shutter_lens"][0]),
+                          float(c["camera.shutter_lens"][1]), float(c["camera.shutter_lens"][2]), float(c["camera.shutter_lens"][3]))
+    film = abi.make_film(int(si[0]), int(si[1]), c["film.filter_table"], float(c["film.filter_width"][0]), float(c["film.filter_width"][1]))
+    smp = abi.make_sampler(int(si[0]), int(si[1]), int(si[2]), int(si[3]), float(c["film.filter_width"][0]), float(c["film.filter_width"][1]),
+                           n1d=tuple(int(v) for v in c["sampler.n1d"]), n2d=tuple(int(v) for v in c["sampler.n2d"]),
+                           tau_index=int(si[4]), scatter_index=int(si[5]))
+    return s, p, cam, film, smp, c
+
+
 def rel_l2(a, b, axis=-1, floor=1e-30):
     """Per-row relative L2 error ||a-b|| / max(||b||, floor)."""
     a = np.asarray(a, np.float64)

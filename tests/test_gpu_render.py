@@ -1,0 +1,225 @@
+"""GPU parity of the tile driver through the C ABI: pvol_render_tasks_device runs whole
+SamplerRendererTasks -- LD sampler, perspective camera, Scene::Intersect clip, Li, image film -- on the device.
+Checked against the golden reference captures (tests/golden/render_*.bin, made by oracle/ref_capture `render`
+from the reference's own objects) and against the oracle on larger seeded inputs.
+Bars: sampler values, rays, RNG stream positions bit-exact; radiance <= 1e-4 rel. L2; film <= 1e-4."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import RENDER_CASES, abi, load_photons, load_render_case, load_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _pvol():
+    import importlib
+    return importlib.import_module("cs348b-pbrt_amd.pvol")
+
+
+def _render(torch, pv, cam, film, smp, tasks, n):
+    dev = torch.device("cuda:0")
+    pixels = torch.zeros((film.y_resolution, film.x_resolution, 4), dtype=torch.float32, device=dev)
+    rays = torch.zeros((max(n, 1), 48), dtype=torch.uint8, device=dev)
+    xy = torch.zeros((max(n, 1), 2), dtype=torch.float32, device=dev)
+    xyz = torch.zeros((max(n, 1), 4), dtype=torch.float32, device=dev)
+    streams = torch.zeros((len(tasks), 32), dtype=torch.uint8, device=dev)
+    dbg = abi.RenderDebug(rays.data_ptr(), xy.data_ptr(), xyz.data_ptr(), streams.data_ptr())
+    pv.render_tasks(cam, film, smp, tasks, pixels.data_ptr(), dbg)
+    rgb = torch.zeros((film.y_resolution, film.x_resolution, 3), dtype=torch.float32, device=dev)
+    pv.film_resolve(film, pixels.data_ptr(), rgb.data_ptr())
+    torch.cuda.synchronize()
+    return {"pixels": pixels.cpu().numpy(), "rgb": rgb.cpu().numpy(),
+            "rays": rays.cpu().numpy().view(abi.RAY_DTYPE).reshape(-1)[:n],
+            "xy": xy.cpu().numpy()[:n], "xyzT": xyz.cpu().numpy()[:n],
+            "streams": streams.cpu().numpy().view(abi.STREAM_DTYPE).reshape(-1)}
+
+
+def _make(name, env=None):
+    pvol = _pvol()
+    s, p, cam, film, smp, c = load_render_case(name)
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        pv = pvol.PhotonVolume(p)
+    finally:
+        pass
+    pv.set_scene(abi.SceneHolder(s))
+    tag = RENDER_CASES[name][1]
+    if tag:
+        pv.upload_photons(*load_photons(tag))
+    return pv, s, p, cam, film, smp, c, old
+
+
+def _restore(old):
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _check_against_capture(r, c, film):
+    np.testing.assert_array_equal(r["xy"].ravel(), c["samples.image"])            # LDPixelSample image samples
+    np.testing.assert_array_equal(r["rays"]["time"], c["samples.time"])
+    np.testing.assert_array_equal(r["rays"]["scatter_u"], c["samples.scatter"])
+    np.testing.assert_array_equal(r["rays"]["o"].ravel(), c["rays.o"])            # GenerateRayDifferential
+    np.testing.assert_array_equal(r["rays"]["d"].ravel(), c["rays.d"])
+    np.testing.assert_array_equal(r["rays"]["maxt"], c["rays.t"][1::2])           # Scene::Intersect clip
+    np.testing.assert_array_equal(r["rays"]["rng_skip"], c["rays.skip"])
+    np.testing.assert_array_equal(r["streams"]["end_draw"], c["task.end_draw"])   # every draw of every task accounted for
+    ref = c["xyzT"].reshape(-1, 4).astype(np.float64)
+    got = r["xyzT"].astype(np.float64)
+    scale = max(np.abs(ref[:, :3]).max(), 1e-30)
+    err = np.linalg.norm(got[:, :3] - ref[:, :3], axis=1) / np.maximum(np.linalg.norm(ref[:, :3], axis=1), 1e-6 * scale)
+    assert err.max() <= 1e-4, "per-sample XYZ rel L2 %.3g" % err.max()
+    np.testing.assert_allclose(got[:, 3], ref[:, 3], rtol=1e-4, atol=1e-6)
+    refpix = c["film.pixels"].reshape(film.y_resolution, film.x_resolution, 4)
+    np.testing.assert_allclose(r["pixels"], refpix, rtol=1e-4, atol=1e-5 * np.abs(refpix).max())
+    refrgb = c["film.rgb"].reshape(film.y_resolution, film.x_resolution, 3)
+    np.testing.assert_allclose(r["rgb"], refrgb, rtol=2e-4, atol=1e-4 * np.abs(refrgb).max())
+
+
+@pytest.mark.parametrize("name", list(RENDER_CASES))
+def test_render_tasks_match_reference_capture(torch_cuda, name):
+    pv, s, p, cam, film, smp, c, old = _make(name)
+    try:
+        r = _render(torch_cuda, pv, cam, film, smp, c["tasks"], len(c["samples.time"]))
+        _check_against_capture(r, c, film)
+    finally:
+        pv.close()
+        _restore(old)
+
+
+@pytest.mark.parametrize("name,env", [("vh", {"PVOL_TILE_BATCH_RAYS": "1024"}),            # several task batches
+                                      ("grid16", {"PVOL_SLICE_RAYS": "64"}),               # many slices through the fused pre-pass
+                                      ("pf", {"PVOL_SLICE_RAYS": "64", "PVOL_TILE_BATCH_RAYS": "600"}),
+                                      ("vh", {"PVOL_FORCE_SEQ": "1"})])                    # COUNT pre-pass feeding the stream-sequential kernel
+def test_render_tasks_batches_slices_and_sequential_kernel(torch_cuda, name, env):
+    pv, s, p, cam, film, smp, c, old = _make(name, env)
+    try:
+        r = _render(torch_cuda, pv, cam, film, smp, c["tasks"], len(c["samples.time"]))
+        _check_against_capture(r, c, film)
+    finally:
+        pv.close()
+        _restore(old)
+
+
+def test_render_larger_frame_matches_oracle(torch_cuda, orc):
+    """96x54 at 16 spp, 64 tasks (221 K camera samples): GPU tile driver vs the oracle's SamplerRendererTask loop."""
+    pvol = _pvol()
+    s = load_scene("volumescene_h")
+    p = abi.params_from_blob(s)
+    xres, yres, spp, ntasks = 96, 54, 16, 64
+    cam = abi.perspective_camera(float(s["camera.fov"][0]), xres, yres, s["camera.c2w"])
+    film = abi.make_film(xres, yres, pvol.gaussian_filter_table())
+    smp = abi.make_sampler(xres, yres, spp, ntasks)
+    tasks = np.arange(ntasks, dtype=np.uint32)
+    n = pvol.render_sample_count(smp, tasks)
+    assert n == (xres + 5) * (yres + 5) * spp
+    holder = abi.SceneHolder(s)
+    pv = pvol.PhotonVolume(p)
+    pv.set_scene(holder)
+    pv.upload_photons(*load_photons("vh"))
+    o = orc.Oracle(holder, p)
+    o.set_photons(*load_photons("vh"))
+    try:
+        r = _render(torch_cuda, pv, cam, film, smp, tasks, n)
+        ref = orc.render_tasks(o, cam, film, smp, tasks, n_threads=8)
+        np.testing.assert_array_equal(r["xy"], ref["image_xy"])
+        for f in ("o", "d", "maxt", "time", "scatter_u", "rng_skip"):
+            np.testing.assert_array_equal(r["rays"][f], ref["rays"][f])
+        np.testing.assert_array_equal(r["streams"]["end_draw"], ref["end_draws"])
+        a, b = r["xyzT"].astype(np.float64), ref["xyzT"].astype(np.float64)
+        scale = np.abs(b[:, :3]).max()
+        err = np.linalg.norm(a[:, :3] - b[:, :3], axis=1) / np.maximum(np.linalg.norm(b[:, :3], axis=1), 1e-6 * scale)
+        assert err.max() <= 1e-4
+        np.testing.assert_allclose(r["pixels"], ref["pixels"], rtol=1e-4, atol=1e-5 * np.abs(ref["pixels"]).max())
+        rgb = orc.film_resolve(film, ref["pixels"])
+        np.testing.assert_allclose(r["rgb"], rgb, rtol=2e-4, atol=1e-4 * np.abs(rgb).max())
+    finally:
+        pv.close()
+
+
+def test_disjoint_task_sets_sum_to_the_whole_frame(torch_cuda):
+    """The multi-GPU film reduce: ranks render disjoint task sets into their own pixel buffers and the buffers add up
+    (bench.py --strong all-reduces them over RCCL) to the single-rank film."""
+    torch = torch_cuda
+    pv, s, p, cam, film, smp, c, old = _make("vh")
+    try:
+        tasks = np.asarray(c["tasks"], np.uint32)
+        dev = torch.device("cuda:0")
+        whole = torch.zeros((film.y_resolution, film.x_resolution, 4), dtype=torch.float32, device=dev)
+        pv.render_tasks(cam, film, smp, tasks, whole.data_ptr())
+        parts = []
+        for rank in range(2):
+            px = torch.zeros_like(whole)
+            pv.render_tasks(cam, film, smp, tasks[rank::2], px.data_ptr())
+            parts.append(px)
+        torch.cuda.synchronize()
+        total = (parts[0] + parts[1]).cpu().numpy()
+        np.testing.assert_allclose(total, whole.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(whole.abs().max()))
+    finally:
+        pv.close()
+        _restore(old)
+
+
+def test_film_add_samples_matches_oracle(torch_cuda, orc):
+    """ImageFilm::AddSample on 200 K random samples: clustered runs (one pixel per wave -> wave-reduced atomics),
+    scattered samples (per-lane atomics) and samples outside the image, then WriteRGB."""
+    torch = torch_cuda
+    pvol = _pvol()
+    rng = np.random.default_rng(5)
+    xres, yres = 40, 24
+    film = abi.make_film(xres, yres, pvol.gaussian_filter_table())
+    n_run, run = 2000, 64
+    px = rng.integers(-2, xres + 3, n_run)
+    py = rng.integers(-2, yres + 3, n_run)
+    xy_run = np.stack([np.repeat(px, run) + rng.random(n_run * run), np.repeat(py, run) + rng.random(n_run * run)], 1)
+    xy_scatter = np.stack([rng.uniform(-4, xres + 4, 72000), rng.uniform(-4, yres + 4, 72000)], 1)
+    xy = np.concatenate([xy_run, xy_scatter]).astype(np.float32)
+    xyz = rng.random((len(xy), 4)).astype(np.float32)
+    s = load_scene("volumescene_h")
+    pv = pvol.PhotonVolume(abi.params_from_blob(s))
+    try:
+        dev = torch.device("cuda:0")
+        dxy, dxyz = torch.from_numpy(xy).to(dev), torch.from_numpy(xyz).to(dev)
+        pixels = torch.zeros((yres, xres, 4), dtype=torch.float32, device=dev)
+        pv.film_add_samples(film, dxy.data_ptr(), dxyz.data_ptr(), 4, len(xy), pixels.data_ptr())
+        rgb = torch.zeros((yres, xres, 3), dtype=torch.float32, device=dev)
+        pv.film_resolve(film, pixels.data_ptr(), rgb.data_ptr())
+        torch.cuda.synchronize()
+        ref = orc.film_add_samples(film, xy, xyz)
+        np.testing.assert_allclose(pixels.cpu().numpy(), ref, rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(rgb.cpu().numpy(), orc.film_resolve(film, ref), rtol=1e-4, atol=1e-4)
+        assert ref[..., 3].min() > 0
+    finally:
+        pv.close()
+
+
+def test_render_rejects_what_it_cannot_do(torch_cuda):
+    pvol = _pvol()
+    pv, s, p, cam, film, smp, c, old = _make("vh")
+    try:
+        px = torch_cuda.zeros((film.y_resolution, film.x_resolution, 4), dtype=torch_cuda.float32, device="cuda:0")
+        lens = abi.make_camera(c["camera.raster_to_camera"], c["camera.camera_to_world"], lens_radius=0.1)
+        with pytest.raises(pvol.PvolError):
+            pv.render_tasks(lens, film, smp, c["tasks"], px.data_ptr())          # thin-lens camera: unsupported
+        bad = abi.make_sampler(film.x_resolution, film.y_resolution, 3, 8)
+        with pytest.raises(pvol.PvolError):
+            pv.render_tasks(cam, film, bad, c["tasks"], px.data_ptr())           # pixel_samples not a power of two
+        with pytest.raises(pvol.PvolError):
+            pv.render_tasks(cam, film, smp, [smp.n_tasks], px.data_ptr())        # task id out of range
+    finally:
+        pv.close()
+        _restore(old)

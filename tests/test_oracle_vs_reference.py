@@ -7,7 +7,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLD, LI_CASES, TRANS_CASES, abi, blob, load_li_case, load_photons, load_scene, rel_l2
+from conftest import (GOLD, LI_CASES, RENDER_CASES, TRANS_CASES, abi, blob, load_li_case, load_photons, load_render_case,
+                      load_scene, rel_l2)
 
 F = C.POINTER(C.c_float)
 U = C.POINTER(C.c_uint32)
@@ -231,3 +232,51 @@ def test_shooter_is_deterministic_and_task_mode_differs(orc):
     P, W, A = o.get_photons()
     gp, gw, ga = load_photons("pf")
     assert (P == gp).all() and (W == gw).all() and (A == ga).all()
+
+
+# ---------------------------------------------------------------- tile driver
+@pytest.mark.parametrize("name", list(RENDER_CASES))
+def test_render_task_records_match_reference(orc, name):
+    """LDSampler + PerspectiveCamera + Scene::Intersect + Li + ImageFilm, walked in SamplerRendererTask::Run order:
+    every per-sample record, every stream position and the film are bit-identical to the reference's."""
+    s, p, cam, film, smp, c = load_render_case(name)
+    assert [smp.x_start, smp.x_end, smp.y_start, smp.y_end] == list(c["sampler.extent"])   # Film::GetSampleExtent
+    for i, t in enumerate(c["tasks"]):
+        assert orc.sub_window(smp, int(t)) == list(c["task.window"][4 * i:4 * i + 4])     # Sampler::ComputeSubWindow
+    o = orc.Oracle(abi.SceneHolder(s), p)
+    tag = RENDER_CASES[name][1]
+    if tag:
+        o.set_photons(*load_photons(tag))
+    r = orc.render_tasks(o, cam, film, smp, c["tasks"])
+    assert r["n_samples"] == len(c["samples.time"]) > 0
+    np.testing.assert_array_equal(r["image_xy"].ravel(), c["samples.image"])
+    np.testing.assert_array_equal(r["rays"]["time"], c["samples.time"])
+    np.testing.assert_array_equal(r["rays"]["scatter_u"], c["samples.scatter"])
+    np.testing.assert_array_equal(r["rays"]["o"].ravel(), c["rays.o"])
+    np.testing.assert_array_equal(r["rays"]["d"].ravel(), c["rays.d"])
+    np.testing.assert_array_equal(r["rays"]["mint"], c["rays.t"][0::2])
+    np.testing.assert_array_equal(r["rays"]["maxt"], c["rays.t"][1::2])
+    np.testing.assert_array_equal(r["rays"]["rng_skip"], c["rays.skip"])
+    np.testing.assert_array_equal(r["end_draws"], c["task.end_draw"])
+    np.testing.assert_array_equal(r["xyzT"].ravel(), c["xyzT"])
+    np.testing.assert_array_equal(r["pixels"].ravel(), c["film.pixels"])
+    np.testing.assert_array_equal(orc.film_resolve(film, r["pixels"]).ravel(), c["film.rgb"])
+    assert np.isfinite(c["film.rgb"]).all() and c["film.rgb"].max() > 0
+
+
+def test_ld_pixel_sample_and_filter_table_match_reference(orc):
+    s, p, cam, film, smp, c = load_render_case("vh")
+    np.testing.assert_array_equal(orc.gaussian_filter_table(2.0, 2.0, 2.0), c["film.filter_table"])
+    # first pixel of task 0: the sampler's draws precede everything else in the stream
+    w = list(c["task.window"][:4])
+    ps, draws = orc.ld_pixel_sample(smp, w[0], w[2], seed=int(c["tasks"][0]))
+    n = smp.pixel_samples
+    assert draws == int(c["rays.skip"][0]) == 7 + 10 * n     # 2+2n, 2+2n, 1+2n, 2 x (1+2n)
+    np.testing.assert_array_equal(ps["imageX"], c["samples.image"][0:2 * n:2])
+    np.testing.assert_array_equal(ps["imageY"], c["samples.image"][1:2 * n:2])
+    np.testing.assert_array_equal(ps["lensU"], c["samples.lens"][0:2 * n:2])
+    np.testing.assert_array_equal(ps["tau"], c["samples.tau"][:n])
+    np.testing.assert_array_equal(ps["scatter"], c["samples.scatter"][:n])
+    # the fp32 camera helper used by bench/tests agrees with the reference's matrices
+    pc = abi.perspective_camera(float(s["camera.fov"][0]), film.x_resolution, film.y_resolution, c["camera.camera_to_world"])
+    np.testing.assert_allclose(np.array(pc.raster_to_camera), c["camera.raster_to_camera"], rtol=1e-6, atol=1e-6)

@@ -3,10 +3,12 @@
 (ray march + k-NN photon gather, PhotonVolumeIntegrator::Li) on config[1]:
 projectScene/volumescene (homogeneous variant) at 1280x720, 256 spp, 1 M volume photons.
 
-One "step" = one pass of the hot path over the whole frame's camera samples (incl. the +-2 px filter
-apron: 1284 x 724 x 256 = 238 M Li() calls), inputs resident in HBM before the timed region.
-N > 1: the reference's render tiles (one MT19937 stream each) are sharded over ranks, photon map
-replicated, no data-path collective; value = samples of all ranks / max-over-ranks time.
+One "step" = one pass of the hot path over the whole frame's camera samples (incl. the filter apron:
+1285 x 725 x 256 = 238.5 M Li() calls), everything resident in HBM: the default `--driver tile` runs whole
+SamplerRendererTasks on the device (LD sampler + camera pre-pass, Li, film), `--driver batch` times Li() alone
+over pre-built rays.  N > 1: the reference's render tasks (one MT19937 stream each) are sharded over ranks,
+photon map replicated; weak scaling (default) has no data-path collective, `--strong` all-reduces the film over
+RCCL; value = samples of all ranks / max-over-ranks time.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -42,14 +44,19 @@ def round_up_pow2(v):
 def frame_tiles(xres, yres):
     """The reference's render tiles over the sample extent (film/image.cpp:157-166: pixels +- filter
     width 2; renderers/samplerrenderer.cpp:206-208 with <= 128 cores; core/sampler.cpp:55-74)."""
-    x_lo, x_hi, y_lo, y_hi = -2, xres + 2, -2, yres + 2
+    # GetSampleExtent: Floor2Int(0.5 - 2) = -2 ... Ceil2Int(0.5 + res + 2) = res + 3
+    x_lo, x_hi, y_lo, y_hi = -2, xres + 3, -2, yres + 3
     n_tiles = round_up_pow2(max(32 * 1, xres * yres // 256))
     nx, ny = tile_grid(n_tiles, x_hi - x_lo, y_hi - y_lo)
     tids = np.arange(n_tiles)
     tx, ty = tids % nx, tids // nx
-    fx = lambda t: np.floor(x_lo + (x_hi - x_lo) * t).astype(np.int64)   # Lerp + Floor2Int, sampler.cpp:66-73
-    fy = lambda t: np.floor(y_lo + (y_hi - y_lo) * t).astype(np.int64)
-    return fx(tx / nx), fx((tx + 1) / nx), fy(ty / ny), fy((ty + 1) / ny), n_tiles
+    f32 = np.float32
+
+    def lerp_floor(k, n, lo, hi):   # Floor2Int(Lerp(float(k)/float(n), lo, hi)) in fp32, sampler.cpp:66-73
+        t = k.astype(f32) / f32(n)
+        return np.floor((f32(1) - t) * f32(lo) + t * f32(hi)).astype(np.int64)
+    return (lerp_floor(tx, nx, x_lo, x_hi), lerp_floor(tx + 1, nx, x_lo, x_hi), lerp_floor(ty, ny, y_lo, y_hi),
+            lerp_floor(ty + 1, ny, y_lo, y_hi), n_tiles)
 
 
 def synth_photons(n, seed=348):
@@ -170,6 +177,42 @@ def cpu_baseline(scene, params, photons, xres, yres, budget_s=15.0):
                       (done, elapsed, t_build, ctr["n_nodes_visited"] / max(1, ctr["n_lookups"]), ctr["n_kept"] / max(1, ctr["n_lookups"]))}, ctr
 
 
+def cpu_baseline_render(scene, params, photons, cam, film, smp, budget_s=20.0):
+    """CPU baseline of the SAME pipeline (tile driver): the oracle's SamplerRendererTask loop (LD sampler, camera,
+    Li with the kd-tree gather, film) on random whole render tasks of the same frame, all host cores, ~20 s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    pkg = importlib.import_module("cs348b-pbrt_amd")
+    abi = pkg.abi
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    o = orc.Oracle(abi.SceneHolder(scene), params)
+    t0 = time.time()
+    o.set_photons(*photons)
+    t_build = time.time() - t0
+    o.counters(reset=True)
+    rng = np.random.default_rng(7)
+    n_tasks = smp.n_tasks
+    # bounded sample: start from ~0.25 M samples (a few seconds at ~0.04 Msamples/s) and double while a batch stays short
+    per_task = (film.x_resolution + 5) * (film.y_resolution + 5) * smp.pixel_samples / n_tasks
+    batch = int(max(1, min(n_tasks, round(250000.0 / per_task))))
+    done, elapsed = 0, 0.0
+    while elapsed < budget_s:
+        pick = rng.choice(n_tasks, min(batch, n_tasks), replace=False).astype(np.uint32)
+        t0 = time.time()
+        r = orc.render_tasks(o, cam, film, smp, pick, records=False, n_threads=cores)
+        dt = time.time() - t0
+        done += r["n_samples"]
+        elapsed += dt
+        if dt < 3.0:
+            batch *= 2
+    ctr = o.counters()
+    return {"value": done / elapsed / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d camera samples = random whole render tasks of the same frame through the oracle's SamplerRendererTask loop "
+                      "(LDSampler, camera, Li with the kd-tree gather of core/kdtree.h, ImageFilm; same scene/photon map/params), "
+                      "%.1f s on %d threads; kd build %.1f s; V=%.0f nodes, K=%.1f photons per lookup" %
+                      (done, elapsed, cores, t_build, ctr["n_nodes_visited"] / max(1, ctr["n_lookups"]), ctr["n_kept"] / max(1, ctr["n_lookups"]))}, ctr
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,7 +229,12 @@ def main():
                     help="shoot: device photon shooter (pvol_preprocess); synth: resampled committed map")
     ap.add_argument("--shoot-tasks", type=int, default=16384, help="virtual PhotonShootingTasks of the device shooter")
     ap.add_argument("--strong", action="store_true",
-                    help="N>1: partition ONE frame's tiles over the ranks (strong scaling) instead of one frame per rank")
+                    help="N>1: partition ONE frame's render tasks over the ranks and all-reduce the film (strong scaling) "
+                         "instead of one frame per rank")
+    ap.add_argument("--driver", choices=["tile", "batch"], default="tile",
+                    help="tile: whole SamplerRendererTasks on the device (LD sampler, camera, Li, film; pvol_render_tasks_device); "
+                         "batch: Li() only over pre-built synthetic camera rays (pvol_li_batch_device)")
+    ap.add_argument("--save-image", default="", help="tile driver: write the resolved RGB film of the last step as .npy")
     args = ap.parse_args()
 
     import torch
@@ -222,22 +270,39 @@ def main():
 
     x0s, x1s, y0s, y1s, n_tiles = frame_tiles(args.xres, args.yres)
     if args.strong:
-        mine = np.arange(rank, n_tiles, world)      # round-robin keeps every rank's tiles spread over the frame
+        mine = np.arange(rank, n_tiles, world)      # round-robin keeps every rank's tasks spread over the frame
     else:
         mine = np.arange(n_tiles)                   # weak scaling: every rank renders a whole frame of its own
-    tiles = (x0s[mine], x1s[mine], y0s[mine], y1s[mine])
-    rays, counts = build_rays(torch, dev, scene, args.xres, args.yres, args.spp, tiles, seed=1234 + rank)
-    n_rays = int(counts.sum())
-    st = abi.make_streams(mine.astype(np.uint32), counts.astype(np.uint32))   # RNG(taskNum), samplerrenderer.cpp:73
-    d_streams = torch.from_numpy(st.view(np.uint8).reshape(len(st), 32).copy()).to(dev)
-    d_out = torch.zeros((n_rays, 4), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
     if args.stats:
         pv.enable_stats(True)
 
-    stream = torch.cuda.current_stream().cuda_stream
+    cam = film = smp = None
+    if args.driver == "tile":
+        cam = abi.perspective_camera(float(scene["camera.fov"][0]), args.xres, args.yres, scene["camera.c2w"])
+        film = abi.make_film(args.xres, args.yres, pvol.gaussian_filter_table())
+        smp = abi.make_sampler(args.xres, args.yres, args.spp, n_tiles)
+        task_ids = mine.astype(np.uint32)
+        n_rays = pvol.render_sample_count(smp, task_ids)
+        d_pixels = torch.zeros((args.yres, args.xres, 4), dtype=torch.float32, device=dev)
+        d_rgb = torch.zeros((args.yres, args.xres, 3), dtype=torch.float32, device=dev)
 
-    def step():
-        pv.li_device(rays.data_ptr(), n_rays, d_streams.data_ptr(), len(st), abi.OUT_XYZ, d_out.data_ptr(), 0, stream)
+        def step():
+            d_pixels.zero_()
+            pv.render_tasks(cam, film, smp, task_ids, d_pixels.data_ptr(), None, stream)
+            if args.strong and dist is not None:
+                dist.all_reduce(d_pixels, op=dist.ReduceOp.SUM)   # the film reduce: 4 floats per pixel over RCCL
+            pv.film_resolve(film, d_pixels.data_ptr(), d_rgb.data_ptr(), stream)
+    else:
+        tiles = (x0s[mine], x1s[mine], y0s[mine], y1s[mine])
+        rays, counts = build_rays(torch, dev, scene, args.xres, args.yres, args.spp, tiles, seed=1234 + rank)
+        n_rays = int(counts.sum())
+        st = abi.make_streams(mine.astype(np.uint32), counts.astype(np.uint32))   # RNG(taskNum), samplerrenderer.cpp:73
+        d_streams = torch.from_numpy(st.view(np.uint8).reshape(len(st), 32).copy()).to(dev)
+        d_out = torch.zeros((n_rays, 4), dtype=torch.float32, device=dev)
+
+        def step():
+            pv.li_device(rays.data_ptr(), n_rays, d_streams.data_ptr(), len(st), abi.OUT_XYZ, d_out.data_ptr(), 0, stream)
 
     def barrier():
         if dist is not None:
@@ -265,29 +330,43 @@ def main():
     else:
         total_rays = n_rays
     kms, launches = pv.kernel_time_ms()
-    checksum = float(d_out[:, :3].double().sum().item())
+    if args.driver == "tile":
+        checksum = float(d_rgb.double().sum().item())
+        if args.save_image and rank == 0:
+            np.save(args.save_image, d_rgb.cpu().numpy())
+    else:
+        checksum = float(d_out[:, :3].double().sum().item())
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = total_rays * args.steps / dt / 1e6
+        if args.driver == "tile":
+            what = ("whole SamplerRendererTasks on the device: LD sampler + perspective camera + Scene::Intersect clip (pre-pass kernel), "
+                    "Li (march + gather), ImageFilm::AddSample + WriteRGB; surface radiance not computed (Ls = Lvi)")
+        else:
+            what = "Li() only over pre-built synthetic camera rays"
         res = {
             "metric": "volumetric photon-gather throughput (camera samples through PhotonVolumeIntegrator::Li per second)",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "volumescene (homogeneous) %dx%d, %d spp, %d volume photons, nused %d, maxdist %.2f, stepsize %.2f; "
-                                   "%d render tiles (MT19937 streams), %d Li() calls per step incl. filter apron" %
+                                   "%d render tasks (MT19937 streams), %d Li() calls per step incl. filter apron" %
                                    (args.xres, args.yres, args.spp, n_photons, params.n_used, params.max_dist, params.step_size,
                                     n_tiles, total_rays),
+                       "step": what,
                        "photon_map": "%s: %d photons (>= %d requested), built in %.1f s (untimed setup)" % (photon_note, n_photons, args.photons, t_map),
-                       "partition": ("one frame, tiles round-robin over %d rank(s)" if args.strong else "one whole frame per rank x %d rank(s)") % world
-                                    + ", photon map replicated, no data-path collective"},
-            "wall_s": dt, "checksum_xyz": checksum,
+                       "partition": (("one frame, render tasks round-robin over %d rank(s), film all-reduced over RCCL" if args.strong
+                                      else "one whole frame per rank x %d rank(s), no data-path collective") % world) + ", photon map replicated"},
+            "wall_s": dt, "checksum": checksum,
         }
-        # roofline of the dominant kernel (li_kernel): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
+        # roofline of the dominant kernel (li_par_kernel): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
         cpu, ctr = (None, None)
         if not args.no_cpu_baseline:
-            cpu, ctr = cpu_baseline(scene, params, photons, args.xres, args.yres)
+            if args.driver == "tile":
+                cpu, ctr = cpu_baseline_render(scene, params, photons, cam, film, smp)
+            else:
+                cpu, ctr = cpu_baseline(scene, params, photons, args.xres, args.yres)
             res["cpu_baseline"] = cpu
         stats = pv.stats() if args.stats else None
         V = (ctr["n_nodes_visited"] / max(1, ctr["n_lookups"])) if ctr else 323.0
@@ -308,7 +387,8 @@ def main():
                            "traffic": traffic, "traffic_source": traffic_src,
                            "kernel": "li_par_kernel", "kernel_avg_ms": kms, "kernel_launches": launches,
                            "algorithmic_bytes_per_lookup": b_lookup, "V": V, "K": K, "lookups_per_sample": steps_per_ray,
-                           "note": "B_lookup = 20*V + 132*K with V, K from the reference-algorithm counters of the CPU baseline on the same inputs"}
+                           "note": "B_lookup = 20*V + 132*K with V, K from the reference-algorithm counters of the CPU baseline on the same inputs; "
+                                   "kernel_avg_ms is the HIP-event time of the march+gather kernel alone, ms_per_step the whole step"}
         if stats:
             res["gpu_counters"] = stats
         print(json.dumps(res))

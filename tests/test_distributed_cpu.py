@@ -116,9 +116,20 @@ def test_tiles_cover_the_sample_extent_once():
     for xres, yres in [(64, 36), (256, 256), (1280, 720)]:
         x0s, x1s, y0s, y1s, n = bench.frame_tiles(xres, yres)
         area = ((x1s - x0s) * (y1s - y0s)).sum()
-        assert area == (xres + 4) * (yres + 4)
-        cover = np.zeros((yres + 4, xres + 4), np.int32)
+        assert area == (xres + 5) * (yres + 5)   # Film::GetSampleExtent: [-2, res + 3)
+        cover = np.zeros((yres + 5, xres + 5), np.int32)
         for a, b, c, d in zip(x0s, x1s, y0s, y1s):
             cover[c + 2:d + 2, a + 2:b + 2] += 1
         assert (cover == 1).all()
     assert bench.frame_tiles(1280, 720)[4] == 4096
+
+
+def test_frame_tiles_equal_the_library_sub_windows():
+    """bench.py's numpy tile lattice == pvol_compute_sub_window == the oracle's (all restate core/sampler.cpp:55-74)."""
+    import importlib
+    pvol = importlib.import_module("cs348b-pbrt_amd.pvol")
+    for xres, yres in [(64, 36), (300, 300), (1280, 720)]:
+        x0s, x1s, y0s, y1s, n = bench.frame_tiles(xres, yres)
+        smp = abi.make_sampler(xres, yres, 4, n)
+        for tsk in range(0, n, max(1, n // 97)):
+            assert pvol.sub_window(smp, tsk) == [x0s[tsk], x1s[tsk], y0s[tsk], y1s[tsk]]

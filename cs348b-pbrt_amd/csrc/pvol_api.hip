@@ -77,6 +77,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     c->dWords = 0;
     c->nCU = 256;
     { const char *fs = getenv("PVOL_FORCE_SEQ"); c->forceSeq = fs && fs[0] == '1'; }
+    { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
@@ -456,8 +457,16 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     if (par) {
         unsigned long long chunks = ((unsigned long long)nRays + 63ull) / 64ull;
         uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
-        e = hipSuccess;
-        if (ok(e)) e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
+        // homogeneous isotropic medium with a photon map and k <= 64: one ray per lane, gathers of 64 rays share a bucket
+        const bool group = !c->noGroup && c->hs.volKind == PVOL_VOLUME_HOMOGENEOUS && c->hs.g == 0.f && c->hs.nPhotons > 0 &&
+                           c->hs.nUsed >= 10 && c->hs.nUsed <= 64 && c->hs.candCap <= 4 * 64;
+        if (group) {
+            unsigned long long gchunks = ((unsigned long long)nRays + 255ull) / 256ull;
+            uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * 8ull);
+            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, stream);
+        } else {
+            e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
+        }
         if (ok(e)) {   // runs only if a ray raised needSeq (gate read on the device: no host sync here)
             a.gated = 1;
             e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
@@ -603,6 +612,7 @@ int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
     out->n_rays = h.nRays; out->n_steps = h.nSteps; out->n_tested = h.nTested; out->n_kept = h.nKept;
     out->n_lookups_lt10 = h.nLookupsLt10; out->n_shadow_unoccluded = h.nShadowUnoccluded;
     out->n_guess_retries = h.pad;
+    out->reserved[0] = h.diag[0]; out->reserved[1] = h.diag[1]; out->reserved[2] = h.diag[2];
     out->cy_search = h.cySearch; out->cy_select = h.cySelect; out->cy_flux = h.cyFlux; out->cy_total = h.cyTotal;
     if (reset && !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) return PVOL_E_NO_DEVICE;
     return PVOL_OK;

@@ -40,6 +40,8 @@ struct GridBuildArgs {
 extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
                                            uint32_t nWaves, hipStream_t stream, bool resolve);
+extern "C" size_t pvol_group_lds_bytes(int candCap);
+extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused);
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
@@ -60,6 +62,7 @@ struct pvol_ctx {
     DevCounters *dCounters;
     uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
     int nCU;
+    bool noGroup;       // PVOL_NO_GROUP=1: keep li_par_kernel (one wave per ray) where li_group_kernel (one ray per lane) would run
     bool forceSeq;      // PVOL_FORCE_SEQ=1: always take the stream-sequential kernel (testing)
     bool statsOn;
     // kernel timing (HIP events on the launch stream)

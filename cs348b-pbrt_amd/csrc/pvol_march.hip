@@ -116,7 +116,7 @@ struct Gather {
     int cap;
 };
 // per-wave work counters (stats build), flushed with one atomic each when the wave retires
-struct WaveCounters { unsigned long long tested, kept, lt10, retries, cySearch, cySelect, cyFlux, rays, steps, unocc; };
+struct WaveCounters { unsigned long long tested, kept, lt10, retries, cySearch, cySelect, cyFlux, rays, steps, unocc, diag0, diag1, diag2; };
 __device__ __forceinline__ unsigned long long stamp() { return __builtin_amdgcn_s_memtime(); }
 
 // Keep the k nearest of the M > k candidates of the LDS list; returns the k-th smallest dist^2 (the new
@@ -950,6 +950,7 @@ __device__ __forceinline__ void flush_counters(DevCounters *c, const WaveCounter
         atomicAdd(&c->cySelect, wc.cySelect);
         atomicAdd(&c->cyFlux, wc.cyFlux);
         atomicAdd(&c->cyTotal, stamp() - t0);
+        atomicAdd(&c->diag[0], wc.diag0); atomicAdd(&c->diag[1], wc.diag1); atomicAdd(&c->diag[2], wc.diag2);
     }
 }
 
@@ -988,7 +989,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_seq_kernel(LiArgs A) {
         rng.mti = MT_N;
         rng_skip<true>(rng, st.start_draw, lane);
     }
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     for (uint32_t k = 0; k < st.n_rays; ++k) {
         const size_t ri = (size_t)st.first_ray + k;
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
     Rng rng;
     rng.mt = 0;
     rng.mti = 0;
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     for (;;) {
         uint32_t chunk = 0;
@@ -1114,7 +1115,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_resolve_kernel(LiArgs A) {
         rng.draws = (A.sliceK == 0) ? st.start_draw : st.end_draw;
         __syncthreads();
     }
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     const bool grid = (S.volKind == PVOL_VOLUME_GRID);
     const uint32_t end = min(st.n_rays, begin + A.sliceM);
     for (uint32_t k = begin; k < end; ++k) {
@@ -1158,7 +1159,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_replay_kernel(LiArgs A) {
     rng.mt = 0;
     rng.mti = 0;
     rng.draws = 0;
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     const bool grid = (S.volKind == PVOL_VOLUME_GRID);
     const uint32_t chunksPerSlice = (A.sliceM + CHUNK_RAYS - 1) / CHUNK_RAYS;
@@ -1231,4 +1232,5 @@ extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve
     return hipGetLastError();
 }
 
+#include "pvol_group_dev.h"
 #include "pvol_tile_dev.h"

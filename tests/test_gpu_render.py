@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def torch_cuda():
     import torch
-    assert torch.cuda.is_available()
+    if not torch.cuda.is_available():
+        torch.cuda.init()   # raises with the reason
     return torch
 
 

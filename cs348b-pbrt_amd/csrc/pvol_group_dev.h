@@ -414,38 +414,40 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 }
                             }
                         }
-                        // ---- pass 3b: flux.  The alpha row of list entry i+1 is in flight while entry i is added.
+                        // ---- pass 3b: flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
+                        // (constant address space: the map is read-only while this kernel runs) and cost no vector-memory
+                        // bandwidth.  Two list entries per iteration, both rows requested before either is used.
+                        nC = __builtin_amdgcn_readfirstlane(nC);
+                        if (lane == 0) L.clist[nC] = (unsigned short)Mb;   // odd count: pair the last entry with a sentinel slot (never a member)
                         __syncthreads();
                         if (nC) {
+                            typedef float nf4 __attribute__((ext_vector_type(4)));
+                            typedef const __attribute__((address_space(4))) nf4 cf4;
                             int quota = quota0;
-                            int cNext = (int)L.clist[0];
-                            f4 Pn = L.pos[cNext];
-                            f4 rowN[8];
-                            {
-                                const f4 *rp = S.alpha4 + (size_t)__float_as_uint(Pn.w) * 8;
+                            for (int i = 0; i < nC; i += 2) {
+                                const f4 PA = L.pos[(int)L.clist[i]], PB = L.pos[(int)L.clist[i + 1]];
+                                cf4 *ra = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(PA.w)) * 8);
+                                cf4 *rb = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(PB.w)) * 8);
+                                nf4 rowA[8], rowB[8];
 #pragma unroll
-                                for (int qq = 0; qq < 8; ++qq) rowN[qq] = rp[qq];
-                            }
-                            for (int i = 0; i < nC; ++i) {
-                                const f4 P = Pn;
-                                f4 row[8];
+                                for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
+                                const float dA = dist2_ref(PA, p), dB = dist2_ref(PB, p);
+                                bool mA = ok && dA < rk;
+                                if (ok && dA == rk && quota > 0) { mA = true; --quota; }
+                                bool mB = ok && dB < rk;
+                                if (ok && dB == rk && quota > 0) { mB = true; --quota; }
+                                // branch-free: acc = fma(row, 0 or 1, acc) is the exact addition for members and a no-op for the rest,
+                                // and leaves the scheduler free to keep both rows' loads ahead of the distance arithmetic
+                                const float fA = mA ? 1.f : 0.f, fB = mB ? 1.f : 0.f;
 #pragma unroll
-                                for (int qq = 0; qq < 8; ++qq) row[qq] = rowN[qq];
-                                if (i + 1 < nC) {
-                                    cNext = (int)L.clist[i + 1];
-                                    Pn = L.pos[cNext];
-                                    const f4 *rp = S.alpha4 + (size_t)__float_as_uint(Pn.w) * 8;
-#pragma unroll
-                                    for (int qq = 0; qq < 8; ++qq) rowN[qq] = rp[qq];
+                                for (int qq = 0; qq < 8; ++qq) {
+                                    acc[4 * qq] = __builtin_fmaf(rowA[qq].x, fA, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowA[qq].y, fA, acc[4 * qq + 1]);
+                                    acc[4 * qq + 2] = __builtin_fmaf(rowA[qq].z, fA, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowA[qq].w, fA, acc[4 * qq + 3]);
                                 }
-                                const float d2 = dist2_ref(P, p);
-                                bool member = ok && d2 < rk;
-                                if (ok && d2 == rk && quota > 0) { member = true; --quota; }
-                                if (member) {
 #pragma unroll
-                                    for (int qq = 0; qq < 8; ++qq) {
-                                        acc[4 * qq] += row[qq].x; acc[4 * qq + 1] += row[qq].y; acc[4 * qq + 2] += row[qq].z; acc[4 * qq + 3] += row[qq].w;
-                                    }
+                                for (int qq = 0; qq < 8; ++qq) {
+                                    acc[4 * qq] = __builtin_fmaf(rowB[qq].x, fB, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowB[qq].y, fB, acc[4 * qq + 1]);
+                                    acc[4 * qq + 2] = __builtin_fmaf(rowB[qq].z, fB, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowB[qq].w, fB, acc[4 * qq + 3]);
                                 }
                             }
                         }
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 }
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
-    return (size_t)candCap * 8 + PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_BINS / 4) * LANES * 4 + GRP_CH * 4 + 9 * 32 * 4 + GRP_CH * 2 + GRP_CAP * 2;
+    return (size_t)candCap * 8 + PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_BINS / 4) * LANES * 4 + GRP_CH * 4 + 9 * 32 * 4 + GRP_CH * 2 + (GRP_CAP + 2) * 2;
 }
 
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {

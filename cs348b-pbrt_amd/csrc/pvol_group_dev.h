@@ -6,7 +6,7 @@
 //   1. STAGE   the photons within sqrt(T) + rho of the group's centre (T = guessed radius^2, rho = spread of the
 //              query points) are found cooperatively in the cell grid and parked in LDS ("LDS-staged bucket");
 //   2. SELECT  every lane finds ITS exact k-th smallest DistanceSquared over the bucket: a histogram pass over
-//              [T/2, T) (byte counters in LDS, one column per lane) locates the bin of the k-th, a second pass keeps
+//              [T/4, T) (byte counters in LDS, one column per lane) locates the bin of the k-th, a second pass keeps
 //              that bin's few values sorted in registers;
 //   3. FLUX    one more pass adds the alpha row of every bucket photon (wave-uniform address: broadcast loads)
 //              into the per-lane 30-bin accumulators of the lanes whose k-NN set contains it.
@@ -16,11 +16,14 @@
 // wave-cooperative lphoton(), which is always exact.  Spectra live as 30 registers per lane.
 #define GRP_CH 256    // rays per chunk (ordered by scatter_u, then cut into groups of 64)
 #define GRP_CAP 512   // bucket capacity (photons)
-#define GRP_BINS 32   // histogram bins over [T/2, T)
+#define GRP_BINS 32   // histogram bins over [T/4, T)
+#define GRP_PITCH (GRP_CAP + 4)   // floats per bucket component (x | y | z | photon index), padded for the 4-wide passes
+#define GRP_MINI 8    // values of the k-th's bin a lane can sort
 #define GRP_WPE 2
 
 struct GroupLds {
-    f4 *pos;                // bucket: xyz, photon index bits in w
+    float *pos;             // bucket, SoA: x[GRP_PITCH] | y | z | photon index bits
+    float *mini;            // [GRP_MINI][64] values of the k-th's bin, one column per lane
     uint32_t *hist;         // [GRP_BINS / 4][64] packed byte counters, one column per lane
     float *ubuf;            // GRP_CH scatter offsets
     unsigned short *order;  // GRP_CH: chunk-local ray index by rank of scatter offset
@@ -29,7 +32,8 @@ struct GroupLds {
 };
 
 // Photons within Rs of c -> LDS bucket.  Returns the count, or -1 if the bucket would overflow.
-__device__ int stage_bucket(const DevScene &S, Gather &G, f4 *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
+__device__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
+    float *bX = bucket, *bY = bucket + GRP_PITCH, *bZ = bucket + 2 * GRP_PITCH, *bI = bucket + 3 * GRP_PITCH;
     const float cell = S.cellSize, inv = S.invCell;
     const float eps = cell * 1e-4f;
     const float T = Rs * Rs;
@@ -110,7 +114,10 @@ __device__ int stage_bucket(const DevScene &S, Gather &G, f4 *bucket, V3 c, floa
                     if (m) {
                         const int add = __popcll(m);
                         if (count + add > GRP_CAP) return -1;
-                        if (acc) bucket[count + (int)lanes_below(m, lane)] = make_float4(P[k].x, P[k].y, P[k].z, __uint_as_float(I[k]));
+                        if (acc) {
+                            const int at = count + (int)lanes_below(m, lane);
+                            bX[at] = P[k].x; bY[at] = P[k].y; bZ[at] = P[k].z; bI[at] = __uint_as_float(I[k]);
+                        }
                         count += add;
                     }
                 }
@@ -124,7 +131,7 @@ __device__ int stage_bucket(const DevScene &S, Gather &G, f4 *bucket, V3 c, floa
             tested += segLen;
         }
     }
-    if (lane < 4) bucket[count + lane] = make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);   // pad to a multiple of four: never inside any radius
+    if (lane < 4) { bX[count + lane] = 3.0e18f; bY[count + lane] = 3.0e18f; bZ[count + lane] = 3.0e18f; bI[count + lane] = 0.f; }   // pad to a multiple of four: never inside any radius
     __syncthreads();
     return count;
 }
@@ -147,8 +154,9 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     M.prevRk = reinterpret_cast<float *>(lds + (size_t)M.G.cap * 8);
     M.G.paint = reinterpret_cast<uint32_t *>(M.prevRk + PREV_N);
     GroupLds L;
-    L.pos = reinterpret_cast<f4 *>(M.G.paint + PAINT_CAP);
-    L.hist = reinterpret_cast<uint32_t *>(L.pos + GRP_CAP + 4);
+    L.pos = reinterpret_cast<float *>(M.G.paint + PAINT_CAP);
+    L.mini = L.pos + 4 * GRP_PITCH;
+    L.hist = reinterpret_cast<uint32_t *>(L.mini + (GRP_MINI + 1) * LANES);
     L.ubuf = reinterpret_cast<float *>(L.hist + (GRP_BINS / 4) * LANES);
     L.cst = L.ubuf + GRP_CH;
     L.order = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
@@ -326,27 +334,37 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     if (STATS && Mb < 0) wc.diag2 += __popcll(needMask);
                     if (Mb >= 0) {
                         const unsigned long long tp1 = STATS ? stamp() : 0ull;
-                        // ---- pass 1: per-lane histogram of DistanceSquared over [T/2, T).  The bucket is padded to a
-                        // multiple of four with far-away sentinels, so the passes run four LDS reads ahead of the arithmetic.
-                        const float Tlo = 0.5f * Tl;
+                        typedef float nf4 __attribute__((ext_vector_type(4)));
+                        const float *bX = L.pos, *bY = L.pos + GRP_PITCH, *bZ = L.pos + 2 * GRP_PITCH, *bI = L.pos + 3 * GRP_PITCH;
+                        const nf4 px4 = {p.x, p.x, p.x, p.x}, py4 = {p.y, p.y, p.y, p.y}, pz4 = {p.z, p.z, p.z, p.z};
+                        // DistanceSquared(photon.p, p) (kdtree.h:180) of four bucket photons: same operations in the same order per
+                        // element, two elements per packed instruction
+#define GRP_D2X4(c0) ({ const nf4 dx_ = *reinterpret_cast<const nf4 *>(bX + (c0)) - px4, dy_ = *reinterpret_cast<const nf4 *>(bY + (c0)) - py4, \
+                                  dz_ = *reinterpret_cast<const nf4 *>(bZ + (c0)) - pz4; dx_ * dx_ + dy_ * dy_ + dz_ * dz_; })
+                        // ---- pass 1: per-lane histogram of DistanceSquared over [Tl/4, Tl).  The bucket is padded to a
+                        // multiple of four with far-away sentinels.
+                        const float Tlo = 0.25f * Tl;
                         const float scale = (float)GRP_BINS / (Tl - Tlo);
 #pragma unroll
                         for (int wd = 0; wd < GRP_BINS / 4; ++wd) L.hist[wd * LANES + lane] = 0u;
                         int below = 0, cnt = 0;
                         float dmax = 0.f;
+                        const float TlEff = need ? Tl : -1.f;   // lanes without a lookup accept nothing
+                        const uint32_t histBase = (uint32_t)lane;
                         for (int c0 = 0; c0 < Mb; c0 += 4) {
-                            const f4 P0 = L.pos[c0], P1 = L.pos[c0 + 1], P2 = L.pos[c0 + 2], P3 = L.pos[c0 + 3];
-                            const float dd[4] = {dist2_ref(P0, p), dist2_ref(P1, p), dist2_ref(P2, p), dist2_ref(P3, p)};
+                            const nf4 dd = GRP_D2X4(c0);
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < 4; ++u) {   // branch-free: predicates are 0/1 integers, the histogram add is +0 when not counted
                                 const float d2 = dd[u];
-                                const bool inT = need && d2 < Tl;
-                                const bool low = inT && d2 < Tlo;
-                                cnt += inT ? 1 : 0;
-                                below += low ? 1 : 0;
-                                dmax = inT ? fmaxf(dmax, d2) : dmax;
+                                const int inT = d2 < TlEff ? 1 : 0;
+                                const int low = d2 < Tlo ? 1 : 0;
                                 const int bin = min(GRP_BINS - 1, (int)((d2 - Tlo) * scale));
-                                if (inT && !low) atomicAdd(&L.hist[(bin >> 2) * LANES + lane], 1u << ((bin & 3) * 8));
+                                cnt += inT;
+                                below += inT & low;
+                                dmax = fmaxf(dmax, inT ? d2 : 0.f);
+                                const int hb = (inT & (low ^ 1)) ? bin : 0;
+                                const uint32_t inc = (uint32_t)(inT & (low ^ 1)) << ((hb & 3) * 8);
+                                atomicAdd(&L.hist[(uint32_t)(hb >> 2) * LANES + histBase], inc);
                             }
                         }
                         bool ok = need && cnt >= k && below < k;
@@ -367,77 +385,79 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 }
                             }
                         }
-                        ok = ok && bstar >= 0 && binCount <= 6 && cnt < 250;   // byte counters never wrapped: every bin <= cnt < 256
-                        // ---- pass 2: the values of bin bstar, sorted in six registers
-                        float s0 = INFINITY, s1 = INFINITY, s2 = INFINITY, s3 = INFINITY, s4 = INFINITY, s5 = INFINITY;
-                        if (__ballot(ok)) {
+                        ok = ok && bstar >= 0 && binCount <= GRP_MINI && cnt < 250;   // byte counters never wrapped: every bin <= cnt < 256
+                        // ---- pass 2: (a) the values of bin bstar go to the lane's mini list; (b) every bucket photon that can
+                        // belong to SOME lane's k-NN set (it lies in a bin <= that lane's bstar) goes to the compact list, in bucket order
+                        int nb = 0, nC = 0;
+                        const bool planLane = ok || shortSet;
+                        if (__ballot(planLane)) {
+                            const float TlPlan = planLane ? Tl : -1.f;
+                            const int bEq = ok ? bstar : -1000;                    // bin whose values are kept (none for short sets)
+                            const int bLe = shortSet ? 1000 : (ok ? bstar : -1000);   // last bin that can hold a member
                             for (int c0 = 0; c0 < Mb; c0 += 4) {
-                                const f4 P0 = L.pos[c0], P1 = L.pos[c0 + 1], P2 = L.pos[c0 + 2], P3 = L.pos[c0 + 3];
-                                const float dd[4] = {dist2_ref(P0, p), dist2_ref(P1, p), dist2_ref(P2, p), dist2_ref(P3, p)};
+                                const nf4 dd = GRP_D2X4(c0);
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
+                                for (int u = 0; u < 4; ++u) {   // branch-free; bins below the histogram range count as -1
                                     const float d2 = dd[u];
-                                    if (ok && d2 >= Tlo && d2 < Tl && min(GRP_BINS - 1, (int)((d2 - Tlo) * scale)) == bstar) {
-                                        float t = d2, lo;
-                                        lo = fminf(s0, t); t = fmaxf(s0, t); s0 = lo;
-                                        lo = fminf(s1, t); t = fmaxf(s1, t); s1 = lo;
-                                        lo = fminf(s2, t); t = fmaxf(s2, t); s2 = lo;
-                                        lo = fminf(s3, t); t = fmaxf(s3, t); s3 = lo;
-                                        lo = fminf(s4, t); t = fmaxf(s4, t); s4 = lo;
-                                        lo = fminf(s5, t); s5 = lo;
-                                    }
+                                    const int inT = d2 < TlPlan ? 1 : 0;
+                                    const int binH = min(GRP_BINS - 1, (int)((d2 - Tlo) * scale));
+                                    const int bin = d2 < Tlo ? -1 : binH;
+                                    const int inBin = inT & (bin == bEq ? 1 : 0);
+                                    L.mini[nb * LANES + lane] = d2;   // kept only if inBin: the slot is overwritten otherwise
+                                    nb += inBin;
+                                    const int possible = inT & (bin <= bLe ? 1 : 0);
+                                    L.clist[nC] = (unsigned short)(c0 + u);   // every lane stores the same value; kept only if some lane may need it
+                                    nC += __ballot(possible != 0) != 0ull ? 1 : 0;
                                 }
                             }
                         }
+                        // sort the mini list (<= GRP_MINI values; absent slots are +inf): odd-even transposition network
+                        float sv[GRP_MINI];
+#pragma unroll
+                        for (int t = 0; t < GRP_MINI; ++t) sv[t] = t < nb ? L.mini[t * LANES + lane] : INFINITY;
+#pragma unroll
+                        for (int rnd = 0; rnd < GRP_MINI; ++rnd) {
+#pragma unroll
+                            for (int t = rnd & 1; t + 1 < GRP_MINI; t += 2) {
+                                const float lo = fminf(sv[t], sv[t + 1]), hi = fmaxf(sv[t], sv[t + 1]);
+                                sv[t] = lo; sv[t + 1] = hi;
+                            }
+                        }
                         const int m = k - cumBelow;   // 1-based rank of the k-th inside its bin
-                        rk = m == 1 ? s0 : m == 2 ? s1 : m == 3 ? s2 : m == 4 ? s3 : m == 5 ? s4 : s5;
-                        int quota0 = k - cumBelow - ((s0 < rk) + (s1 < rk) + (s2 < rk) + (s3 < rk) + (s4 < rk) + (s5 < rk));   // ties at rk taken in bucket order
+                        rk = sv[0];
+                        int nLessIn = 0;
+#pragma unroll
+                        for (int t = 1; t < GRP_MINI; ++t) rk = (m == t + 1) ? sv[t] : rk;
+#pragma unroll
+                        for (int t = 0; t < GRP_MINI; ++t) nLessIn += (sv[t] < rk) ? 1 : 0;
+                        int quota0 = k - cumBelow - nLessIn;   // ties at rk are taken in bucket order
                         ok = ok && rk < Tl;
                         if (shortSet) { ok = true; rk = dmax; quota0 = 256; }
                         const unsigned long long tp3 = STATS ? stamp() : 0ull;
                         if (STATS) wc.cySelect += tp3 - tp1;
-                        // ---- pass 3a: which bucket photons belong to SOME lane's k-NN set -> compact list (bucket order)
-                        int nC = 0;
-                        if (__ballot(ok)) {
-                            int quota = quota0;
-                            for (int c0 = 0; c0 < Mb; c0 += 4) {
-                                const f4 P0 = L.pos[c0], P1 = L.pos[c0 + 1], P2 = L.pos[c0 + 2], P3 = L.pos[c0 + 3];
-                                const float dd[4] = {dist2_ref(P0, p), dist2_ref(P1, p), dist2_ref(P2, p), dist2_ref(P3, p)};
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    bool member = ok && dd[u] < rk;
-                                    if (ok && dd[u] == rk && quota > 0) { member = true; --quota; }
-                                    if (__ballot(member)) {
-                                        if (lane == 0) L.clist[nC] = (unsigned short)(c0 + u);
-                                        ++nC;
-                                    }
-                                }
-                            }
-                        }
-                        // ---- pass 3b: flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
+                        // ---- pass 3: flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
                         // (constant address space: the map is read-only while this kernel runs) and cost no vector-memory
-                        // bandwidth.  Two list entries per iteration, both rows requested before either is used.
+                        // bandwidth.  Two list entries per iteration; acc = fma(row, 0 or 1, acc) is the exact addition for
+                        // members and a no-op for the others, without a branch.
                         nC = __builtin_amdgcn_readfirstlane(nC);
                         if (lane == 0) L.clist[nC] = (unsigned short)Mb;   // odd count: pair the last entry with a sentinel slot (never a member)
                         __syncthreads();
-                        if (nC) {
-                            typedef float nf4 __attribute__((ext_vector_type(4)));
+                        if (nC && __ballot(ok)) {
                             typedef const __attribute__((address_space(4))) nf4 cf4;
                             int quota = quota0;
                             for (int i = 0; i < nC; i += 2) {
-                                const f4 PA = L.pos[(int)L.clist[i]], PB = L.pos[(int)L.clist[i + 1]];
-                                cf4 *ra = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(PA.w)) * 8);
-                                cf4 *rb = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(PB.w)) * 8);
+                                const int ca = (int)L.clist[i], cb2 = (int)L.clist[i + 1];
+                                const float ax = bX[ca], ay = bY[ca], az = bZ[ca], bx = bX[cb2], by = bY[cb2], bz = bZ[cb2];
+                                cf4 *ra = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[ca])) * 8);
+                                cf4 *rb = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[cb2])) * 8);
                                 nf4 rowA[8], rowB[8];
 #pragma unroll
                                 for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
-                                const float dA = dist2_ref(PA, p), dB = dist2_ref(PB, p);
+                                const float dA = dist2_ref(make_float4(ax, ay, az, 0.f), p), dB = dist2_ref(make_float4(bx, by, bz, 0.f), p);
                                 bool mA = ok && dA < rk;
                                 if (ok && dA == rk && quota > 0) { mA = true; --quota; }
                                 bool mB = ok && dB < rk;
                                 if (ok && dB == rk && quota > 0) { mB = true; --quota; }
-                                // branch-free: acc = fma(row, 0 or 1, acc) is the exact addition for members and a no-op for the rest,
-                                // and leaves the scheduler free to keep both rows' loads ahead of the distance arithmetic
                                 const float fA = mA ? 1.f : 0.f, fB = mB ? 1.f : 0.f;
 #pragma unroll
                                 for (int qq = 0; qq < 8; ++qq) {
@@ -451,6 +471,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 }
                             }
                         }
+#undef GRP_D2X4
                         if (ok) { done = true; viaPlan = true; if (shortSet) nFoundLane = cnt; }
                         if (STATS) { wc.kept += (unsigned long long)__popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
                     }
@@ -589,7 +610,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 }
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
-    return (size_t)candCap * 8 + PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_BINS / 4) * LANES * 4 + GRP_CH * 4 + 9 * 32 * 4 + GRP_CH * 2 + (GRP_CAP + 2) * 2;
+    return (size_t)candCap * 8 + PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 4) * LANES * 4 + GRP_CH * 4 + 9 * 32 * 4 + GRP_CH * 2 + (GRP_CAP + 2) * 2;
 }
 
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {

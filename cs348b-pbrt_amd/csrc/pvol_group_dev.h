@@ -147,20 +147,23 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
     MarchLds M;
+    // LDS plan (19.9 KB with candCap 256: eight waves per CU): prevRk | paint | bucket | mini | hist | cst | clist.
+    // The fallback lookup's candidate arrays alias the bucket (dead by then), the chunk-ordering scratch aliases mini + hist
+    // (used only between chunks; the groups' ray indices are taken into registers first).
     M.G.cap = S.candCap;
-    M.G.cd = reinterpret_cast<float *>(lds);
-    M.G.ci = reinterpret_cast<uint32_t *>(lds + (size_t)M.G.cap * 4);
     M.lightNum = 0;
-    M.prevRk = reinterpret_cast<float *>(lds + (size_t)M.G.cap * 8);
+    M.prevRk = reinterpret_cast<float *>(lds);
     M.G.paint = reinterpret_cast<uint32_t *>(M.prevRk + PREV_N);
     GroupLds L;
     L.pos = reinterpret_cast<float *>(M.G.paint + PAINT_CAP);
+    M.G.cd = L.pos;                                                  // candCap * 8 <= 4 * GRP_PITCH * 4 (checked on the host)
+    M.G.ci = reinterpret_cast<uint32_t *>(L.pos + M.G.cap);
     L.mini = L.pos + 4 * GRP_PITCH;
     L.hist = reinterpret_cast<uint32_t *>(L.mini + (GRP_MINI + 1) * LANES);
-    L.ubuf = reinterpret_cast<float *>(L.hist + (GRP_BINS / 4) * LANES);
-    L.cst = L.ubuf + GRP_CH;
-    L.order = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
-    L.clist = L.order + GRP_CH;
+    L.ubuf = L.mini;                                                 // GRP_CH floats
+    L.order = reinterpret_cast<unsigned short *>(L.ubuf + GRP_CH);   // GRP_CH shorts; both fit in mini + hist
+    L.cst = reinterpret_cast<float *>(L.hist + (GRP_BINS / 4) * LANES);
+    L.clist = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
     const int q = lane & 7;
     const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
@@ -214,9 +217,17 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
             L.order[rank] = (unsigned short)i;
         }
         __syncthreads();
+        unsigned short ordReg[GRP_CH / LANES];
+#pragma unroll
+        for (int g = 0; g < GRP_CH / LANES; ++g) ordReg[g] = (g * LANES + lane < nIn) ? L.order[g * LANES + lane] : (unsigned short)0;
+        __syncthreads();
+#pragma unroll 1
         for (int g0 = 0; g0 < nIn; g0 += LANES) {
             const bool have = g0 + lane < nIn;
-            const size_t ri = (size_t)r0 + (have ? (size_t)L.order[g0 + lane] : 0u);
+            unsigned short ordMine = ordReg[0];
+#pragma unroll
+            for (int g = 1; g < GRP_CH / LANES; ++g) ordMine = (g0 == g * LANES) ? ordReg[g] : ordMine;
+            const size_t ri = (size_t)r0 + (have ? (size_t)ordMine : 0u);
             pvol_ray pr = A.rays[ri];
             V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
             RayD ray;
@@ -610,7 +621,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 }
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
-    return (size_t)candCap * 8 + PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 4) * LANES * 4 + GRP_CH * 4 + 9 * 32 * 4 + GRP_CH * 2 + (GRP_CAP + 2) * 2;
+    (void)candCap;   // the fallback candidate arrays alias the bucket
+    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 4) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 2) * 2;
 }
 
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {

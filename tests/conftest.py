@@ -7,6 +7,11 @@ import sys
 import numpy as np
 import pytest
 
+try:   # torch ships its own HIP runtime: load it BEFORE libpvol.so pulls in /opt/rocm's, or torch finds no GPU afterwards
+    import torch  # noqa: F401
+except Exception:   # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 sys.path.insert(0, ROOT)

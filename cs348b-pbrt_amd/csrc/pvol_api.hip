@@ -78,6 +78,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     c->nCU = 256;
     { const char *fs = getenv("PVOL_FORCE_SEQ"); c->forceSeq = fs && fs[0] == '1'; }
     { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
+    { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 8; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
@@ -462,7 +463,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
                            c->hs.nUsed >= 10 && c->hs.nUsed <= 64 && c->hs.candCap <= 4 * 64;
         if (group) {
             unsigned long long gchunks = ((unsigned long long)nRays + 255ull) / 256ull;
-            uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * 8ull);
+            uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
             e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, stream);
         } else {
             e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);

@@ -330,6 +330,7 @@ def main():
     else:
         total_rays = n_rays
     kms, launches = pv.kernel_time_ms()
+    kernel_name = pv.march_kernel_name()
     if args.driver == "tile":
         checksum = float(d_rgb.double().sum().item())
         if args.save_image and rank == 0:
@@ -360,7 +361,7 @@ def main():
                                       else "one whole frame per rank x %d rank(s), no data-path collective") % world) + ", photon map replicated"},
             "wall_s": dt, "checksum": checksum,
         }
-        # roofline of the dominant kernel (li_par_kernel): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
+        # roofline of the dominant kernel (li_group_kernel here): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
         cpu, ctr = (None, None)
         if not args.no_cpu_baseline:
             if args.driver == "tile":
@@ -385,7 +386,7 @@ def main():
             traffic_src = tj["source"]
         res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "traffic_source": traffic_src,
-                           "kernel": "li_par_kernel", "kernel_avg_ms": kms, "kernel_launches": launches,
+                           "kernel": kernel_name, "kernel_avg_ms": kms, "kernel_launches": launches,
                            "algorithmic_bytes_per_lookup": b_lookup, "V": V, "K": K, "lookups_per_sample": steps_per_ray,
                            "note": "B_lookup = 20*V + 132*K with V, K from the reference-algorithm counters of the CPU baseline on the same inputs; "
                                    "kernel_avg_ms is the HIP-event time of the march+gather kernel alone, ms_per_step the whole step"}

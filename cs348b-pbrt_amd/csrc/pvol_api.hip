@@ -465,7 +465,9 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             unsigned long long gchunks = ((unsigned long long)nRays + 255ull) / 256ull;
             uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
             e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, stream);
+            c->lastKernel = "li_group_kernel";
         } else {
+            c->lastKernel = "li_par_kernel";
             e = pvol_launch_li_par(&a, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream);
         }
         if (ok(e)) {   // runs only if a ray raised needSeq (gate read on the device: no host sync here)
@@ -473,6 +475,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
         }
     } else if (sliced) {
+        c->lastKernel = "li_replay_kernel";
         e = hipSuccess;
         unsigned long long chunks = (unsigned long long)((sliceM + 63) / 64) * nStreams;
         uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
@@ -484,6 +487,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
                                                 tile == 0);
         }
     } else {
+        c->lastKernel = "li_seq_kernel";
         e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
     }
     hipEventRecord(ev.second, stream);
@@ -618,6 +622,8 @@ int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
     if (reset && !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) return PVOL_E_NO_DEVICE;
     return PVOL_OK;
 }
+
+const char *pvol_march_kernel_name(pvol_ctx *c) { return c ? c->lastKernel : ""; }
 
 int pvol_kernel_time_ms(pvol_ctx *c, double *avgMs, uint64_t *launches, int reset) {
     if (!c || !avgMs) return PVOL_E_INVALID;

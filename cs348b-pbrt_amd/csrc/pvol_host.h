@@ -62,6 +62,7 @@ struct pvol_ctx {
     DevCounters *dCounters;
     uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
     int nCU;
+    const char *lastKernel = "";
     int groupWavesPerCU; // resident li_group_kernel waves per CU (LDS plan: 8); PVOL_GROUP_WAVES overrides
     bool noGroup;       // PVOL_NO_GROUP=1: keep li_par_kernel (one wave per ray) where li_group_kernel (one ray per lane) would run
     bool forceSeq;      // PVOL_FORCE_SEQ=1: always take the stream-sequential kernel (testing)

@@ -57,6 +57,8 @@ def lib():
         L.pvol_enable_stats.argtypes = [C.c_void_p, C.c_int]
         L.pvol_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.pvol_get_shoot_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        L.pvol_march_kernel_name.argtypes = [C.c_void_p]
+        L.pvol_march_kernel_name.restype = C.c_char_p
         L.pvol_gaussian_filter_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
         L.pvol_gaussian_filter_table.restype = None
         L.pvol_compute_sub_window.argtypes = [C.POINTER(abi.Sampler), C.c_uint32, C.POINTER(C.c_int32)]
@@ -76,7 +78,7 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
            "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats",
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
-           "pvol_film_add_samples_device", "pvol_film_resolve_device"]
+           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -201,6 +203,9 @@ class PhotonVolume:
         d = {k: int(getattr(s, k)) for k, _ in abi.Stats._fields_ if k != "reserved"}
         d["group_guess_short"], d["group_guess_long"], d["group_plan_skipped"] = (int(v) for v in s.reserved)
         return d
+
+    def march_kernel_name(self):
+        return lib().pvol_march_kernel_name(self._h).decode()
 
     def kernel_time_ms(self, reset=False):
         avg = C.c_double()

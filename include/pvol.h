@@ -301,6 +301,9 @@ int pvol_enable_stats(pvol_ctx *ctx, int on);
 /* Average device time of the dominant (march+gather) kernel over the launches since
  * the last reset, measured with HIP events on the launch stream. */
 int pvol_kernel_time_ms(pvol_ctx *ctx, double *avg_ms, uint64_t *launches, int reset);
+/* Name of the march+gather kernel the last batch was dispatched to ("li_group_kernel", "li_par_kernel",
+ * "li_replay_kernel", "li_seq_kernel"; "" before the first batch): the kernel the time above belongs to. */
+const char *pvol_march_kernel_name(pvol_ctx *ctx);
 
 /* GaussianFilter::Evaluate tabulated as ImageFilm's constructor does (filters/gaussian.h:44-58,
  * film/image.cpp:57-68). */

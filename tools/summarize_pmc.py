@@ -18,16 +18,18 @@ os.makedirs(out, exist_ok=True)
 g = os.path.join(ROOT, "gpurun_out")
 
 agg = collections.defaultdict(float)
+kernels = set()
 for d in sorted(glob.glob(os.path.join(g, tag + "_pmc_*"))):
     files = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
     if not os.path.isdir(d) or not files:
         continue
     f = max(files, key=os.path.getmtime)   # gpurun merges runs: keep the newest pass only
     for r in csv.DictReader(open(f)):
-        if "li_par_kernel" in r["Kernel_Name"]:
+        if "li_group_kernel" in r["Kernel_Name"] or "li_par_kernel" in r["Kernel_Name"]:
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            kernels.add(r["Kernel_Name"].split("<")[0].replace("void ", ""))
 plain = None
-for f in glob.glob(os.path.join(g, tag + "_pmc_*.log")):
+for f in glob.glob(os.path.join(g, tag + "_pmc_*.log")) + glob.glob(os.path.join(g, tag + "_prof_plain.json")):
     for line in open(f, errors="ignore"):
         if line.startswith("{") and "rays" in line:
             plain = json.loads(line)
@@ -36,7 +38,7 @@ if agg and plain:
     fetch_kb, write_kb = agg.get("FETCH_SIZE", 0.0), agg.get("WRITE_SIZE", 0.0)
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0   # FETCH_SIZE counts half the bytes on gfx950 (MI355X_MICROARCH.md, HBM)
     summary = {
-        "kernel": "li_par_kernel", "driver": "tools/pvol_prof (bench.py workload at 2 spp)", "rays": rays,
+        "kernel": "+".join(sorted(kernels)), "driver": "tools/pvol_prof (tools/run_profiles.sh: bench.py scene and photon-map recipe, 640x360 at 64 spp)", "rays": rays,
         "counters": dict(agg),
         "per_ray": {k: v / rays for k, v in agg.items()},
         "l2_hit_rate": agg.get("TCC_HIT_sum", 0) / max(1.0, agg.get("TCC_HIT_sum", 0) + agg.get("TCC_MISS_sum", 0)),

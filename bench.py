@@ -386,10 +386,13 @@ def main():
             traffic_src = tj["source"]
         res["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                            "traffic": traffic, "traffic_source": traffic_src,
+                           "hbm_measured_GBps": (traffic / (kms * 1e-3) / 1e9) if (traffic and kms > 0) else None,
                            "kernel": kernel_name, "kernel_avg_ms": kms, "kernel_launches": launches,
                            "algorithmic_bytes_per_lookup": b_lookup, "V": V, "K": K, "lookups_per_sample": steps_per_ray,
                            "note": "B_lookup = 20*V + 132*K with V, K from the reference-algorithm counters of the CPU baseline on the same inputs; "
-                                   "kernel_avg_ms is the HIP-event time of the march+gather kernel alone, ms_per_step the whole step"}
+                                   "kernel_avg_ms is the HIP-event time of the march+gather kernel alone, ms_per_step the whole step. "
+                                   "frac > 1 means the kernel serves the reference algorithm's bytes from LDS/L2/Infinity Cache: 64 neighbouring "
+                                   "gathers share one staged photon bucket, so the HBM traffic (`traffic`, PMC) is a small fraction of them"}
         if stats:
             res["gpu_counters"] = stats
         print(json.dumps(res))

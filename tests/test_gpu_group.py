@@ -1,0 +1,148 @@
+"""li_group_kernel (one camera ray per lane, 64 gathers sharing an LDS-staged photon bucket) against the oracle and
+against li_par_kernel (one wave per ray) on photon maps dense enough that the bucket plan -- histogram selection of
+each lane's exact k-th distance, scalar-cache flux rows -- carries the lookups (the golden Li() cases use 6 k-photon
+maps whose lookups mostly run at the full radius).  Bars: radiance <= 1e-4 rel. L2 per ray against the oracle,
+RNG draw counts exact, the two GPU kernels within 2e-5 of each other."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, abi, load_scene, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pvol():
+    m = importlib.import_module("cs348b-pbrt_amd.pvol")
+    assert m.lib().pvol_device_count() >= 1
+    return m
+
+
+def _camera_batch(orc, scene, xres, yres, spp, n_tasks, tasks):
+    """Real camera samples of whole render tasks (LD sampler + perspective camera + clip) from the oracle's tile driver."""
+    cam = abi.perspective_camera(float(scene["camera.fov"][0]), xres, yres, scene["camera.c2w"])
+    film = abi.make_film(xres, yres, orc.gaussian_filter_table())
+    smp = abi.make_sampler(xres, yres, spp, n_tasks)
+    o = orc.Oracle(abi.SceneHolder(scene), abi.params_from_blob(scene))   # no photon map: only the rays are wanted
+    r = orc.render_tasks(o, cam, film, smp, np.asarray(tasks, np.uint32))
+    counts = [orc.sub_window(smp, t) for t in tasks]
+    counts = np.array([(w[1] - w[0]) * (w[3] - w[2]) * spp for w in counts], np.uint32)
+    return r["rays"], abi.make_streams(np.asarray(tasks, np.uint32), counts)
+
+
+def _dense_map(pvol, scene, n_photons, n_tasks, **over):
+    p = abi.params_from_blob(scene, n_volume_photons=n_photons, **over)
+    pv = pvol.PhotonVolume(p)
+    pv.set_scene(abi.SceneHolder(scene))
+    pv.preprocess(n_tasks)   # many virtual tasks: the device shooter runs one task per lane
+    return pv, p, pv.download_photons()
+
+
+@pytest.fixture(scope="module")
+def vh_map(pvol):
+    """One 150 k-photon map of the volumescene shot on the device, shared by the tests of this module."""
+    s = load_scene("volumescene_h")
+    pv, p, photons = _dense_map(pvol, s, 150000, 8192)
+    pv.close()
+    return s, p, photons
+
+
+def _ctx(pvol, s, p, photons):
+    pv = pvol.PhotonVolume(p)
+    pv.set_scene(abi.SceneHolder(s))
+    pv.upload_photons(*photons)
+    return pv
+
+
+@pytest.mark.parametrize("scene_name,n_photons,over", [("volumescene_h", 150000, {}),
+                                                       ("shootbench", 60000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2})])
+def test_group_kernel_matches_oracle_on_a_dense_map(pvol, orc, vh_map, scene_name, n_photons, over):
+    """volumescene: distant light; shootbench: a SPOT light through a glass prism's triangles (falloff, 1/d^2, occlusion)."""
+    if scene_name == "volumescene_h":
+        s, p, photons = vh_map
+        pv = _ctx(pvol, s, p, photons)
+    else:
+        s = load_scene(scene_name)
+        pv, p, photons = _dense_map(pvol, s, n_photons, 8192, **over)
+    try:
+        assert pv.photon_count() >= n_photons
+        rays, streams = _camera_batch(orc, s, 640, 360, 64, 4096, [700, 2100])   # ~55 pixels x 64 spp per task
+        assert len(rays) >= 4096
+        pv.enable_stats(True)
+        pv.stats(reset=True)
+        got, gd = pv.li(rays, streams.copy())
+        assert pv.march_kernel_name() == "li_group_kernel"
+        st = pv.stats()
+        o = orc.Oracle(abi.SceneHolder(s), p)
+        o.set_photons(*photons)
+        ref, rd = o.li_batch(rays, streams.copy(), n_threads=8)
+        assert (gd == rd).all()
+        lit = np.linalg.norm(ref[:, :30], axis=1) > 0
+        assert lit.sum() > len(rays) // 4
+        err = rel_l2(got[:, :30], ref[:, :30], floor=1e-12)
+        assert err.max() <= TOL, "rel L2 %.3g at ray %d" % (err.max(), int(err.argmax()))
+        np.testing.assert_allclose(got[:, 30:], ref[:, 30:], rtol=1e-5, atol=1e-7)
+        # the bucket plan, not the fallback, served the bulk of the lookups (each wave's first group starts cold)
+        assert st["n_kept"] > 0.5 * st["n_steps"], st
+        # one stream position per render task, all draws accounted for
+        o_end = streams.copy()
+        o.li_batch(rays, o_end)
+        g_end = streams.copy()
+        pv.li(rays, g_end)
+        assert (g_end["end_draw"] == o_end["end_draw"]).all()
+    finally:
+        pv.close()
+
+
+def test_group_and_per_ray_kernels_agree(pvol, orc, vh_map, monkeypatch):
+    s, p, photons = vh_map
+    pv = _ctx(pvol, s, p, photons)
+    monkeypatch.setenv("PVOL_NO_GROUP", "1")
+    pv1 = pvol.PhotonVolume(p)
+    monkeypatch.delenv("PVOL_NO_GROUP")
+    try:
+        pv1.set_scene(abi.SceneHolder(s))
+        pv1.upload_photons(*photons)
+        rays, streams = _camera_batch(orc, s, 640, 360, 64, 2048, list(range(40, 2048, 400)))
+        assert len(rays) > 15000
+        a, da = pv.li(rays, streams.copy())
+        b, db = pv1.li(rays, streams.copy())
+        assert pv.march_kernel_name() == "li_group_kernel" and pv1.march_kernel_name() == "li_par_kernel"
+        assert (da == db).all()
+        scale = np.abs(b[:, :30]).max()
+        np.testing.assert_allclose(a[:, :30], b[:, :30], rtol=2e-5, atol=1e-6 * scale)
+        np.testing.assert_allclose(a[:, 30:], b[:, 30:], rtol=2e-6)
+        a2, _ = pv.li(rays, streams.copy())
+        assert (a == a2).all()   # wave scheduling changes the guessed radii, never the k-NN sets or the summation order
+    finally:
+        pv.close()
+        pv1.close()
+
+
+def test_ragged_batches_and_rays_that_miss(pvol, orc, vh_map):
+    """Batch sizes around the 64-lane / 256-ray chunk boundaries, rays that miss the volume, several streams per chunk."""
+    s, p, photons = vh_map
+    pv = _ctx(pvol, s, p, photons)
+    o = orc.Oracle(abi.SceneHolder(s), p)
+    o.set_photons(*photons)
+    try:
+        rays, _ = _camera_batch(orc, s, 640, 360, 16, 4096, [1000])
+        miss = rays[:7].copy()
+        miss["d"] = -miss["d"]          # away from the medium
+        rays = np.concatenate([miss, rays])
+        for n in (1, 63, 65, 256, 257, 300):
+            sub = rays[:n].copy()
+            a, b2 = n // 3, n // 3
+            counts = np.array([a, b2, n - a - b2], np.uint32)
+            st = abi.make_streams(np.array([11, 12, 13], np.uint32), counts)
+            got, gd = pv.li(sub, st.copy())
+            ref, rd = o.li_batch(sub, st.copy())
+            assert (gd == rd).all()
+            assert rel_l2(got[:, :30], ref[:, :30], floor=1e-12).max() <= TOL
+            np.testing.assert_allclose(got[:, 30:], ref[:, 30:], rtol=1e-5, atol=1e-7)
+    finally:
+        pv.close()

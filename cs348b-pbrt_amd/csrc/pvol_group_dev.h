@@ -16,15 +16,16 @@
 // wave-cooperative lphoton(), which is always exact.  Spectra live as 30 registers per lane.
 #define GRP_CH 256    // rays per chunk (ordered by scatter_u, then cut into groups of 64)
 #define GRP_CAP 512   // bucket capacity (photons)
-#define GRP_BINS 32   // histogram bins over [T/4, T)
+#define GRP_BINS 64   // histogram bins over [T/4, T), 4-bit counters (eight per LDS word)
 #define GRP_PITCH (GRP_CAP + 4)   // floats per bucket component (x | y | z | photon index), padded for the 4-wide passes
+#define GRP_WIDEN 1.7f   // a lane's search radius^2 may grow to this multiple of its guess where the bucket covers it
 #define GRP_MINI 8    // values of the k-th's bin a lane can sort
 #define GRP_WPE 2
 
 struct GroupLds {
     float *pos;             // bucket, SoA: x[GRP_PITCH] | y | z | photon index bits
     float *mini;            // [GRP_MINI][64] values of the k-th's bin, one column per lane
-    uint32_t *hist;         // [GRP_BINS / 4][64] packed byte counters, one column per lane
+    uint32_t *hist;         // [GRP_BINS / 8][64] packed 4-bit counters, one column per lane
     float *ubuf;            // GRP_CH scatter offsets
     unsigned short *order;  // GRP_CH: chunk-local ray index by rank of scatter offset
     float *cst;             // 9 x 32 floats: sigA, sigS, le, albedo, light-0 intensity, 1/sigS, CIE X, Y, Z weights
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     L.hist = reinterpret_cast<uint32_t *>(L.mini + (GRP_MINI + 1) * LANES);
     L.ubuf = L.mini;                                                 // GRP_CH floats
     L.order = reinterpret_cast<unsigned short *>(L.ubuf + GRP_CH);   // GRP_CH shorts; both fit in mini + hist
-    L.cst = reinterpret_cast<float *>(L.hist + (GRP_BINS / 4) * LANES);
+    L.cst = reinterpret_cast<float *>(L.hist + (GRP_BINS / 8) * LANES);
     L.clist = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
     const int q = lane & 7;
@@ -322,8 +323,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     // mean at this step; the full radius when neither exists.  The bucket covers the largest of them.
                     float gbl = lastRk;
                     if (j < PREV_N) gbl = fmaxf(gbl, M.prevRk[j]);
-                    const float Tl = (gbl > 0.f && gbl * PVOL_GUESS_SCALE < S.maxDistSq) ? gbl * PVOL_GUESS_SCALE : S.maxDistSq;
-                    const bool fullR = !(Tl < S.maxDistSq);
+                    float Tl = (gbl > 0.f && gbl * PVOL_GUESS_SCALE < S.maxDistSq) ? gbl * PVOL_GUESS_SCALE : S.maxDistSq;
+                    bool fullR = !(Tl < S.maxDistSq);
                     float T = need ? Tl : 0.f;
                     T = wave_max(T);
                     int Mb = -1;
@@ -340,6 +341,13 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         const float Rs = (sqrtf(T) + rho) * 1.0001f + 1e-6f;   // superset by the triangle inequality, with rounding slack
                         unsigned long long tst = 0, ts0 = STATS ? stamp() : 0ull;
                         Mb = stage_bucket(S, M.G, L.pos, c, Rs, lane, tst);
+                        // the bucket covers more than this lane asked for when other lanes guessed larger: take it (up to
+                        // GRP_WIDEN x the guess) -- a wider search ball costs this lane nothing and spares it a failed guess
+                        if (need && gbl > 0.f) {
+                            const float cover = (sqrtf(T) + rho) - len(p - c);
+                            Tl = fminf(S.maxDistSq, fmaxf(Tl, fminf(cover * cover, gbl * GRP_WIDEN)));
+                            fullR = !(Tl < S.maxDistSq);
+                        }
                         if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; wc.lt10 += 1; }
                     }
                     if (STATS && Mb < 0) wc.diag2 += __popcll(needMask);
@@ -357,7 +365,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         const float Tlo = 0.25f * Tl;
                         const float scale = (float)GRP_BINS / (Tl - Tlo);
 #pragma unroll
-                        for (int wd = 0; wd < GRP_BINS / 4; ++wd) L.hist[wd * LANES + lane] = 0u;
+                        for (int wd = 0; wd < GRP_BINS / 8; ++wd) L.hist[wd * LANES + lane] = 0u;
                         int below = 0, cnt = 0;
                         float dmax = 0.f;
                         const float TlEff = need ? Tl : -1.f;   // lanes without a lookup accept nothing
@@ -374,8 +382,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 below += inT & low;
                                 dmax = fmaxf(dmax, inT ? d2 : 0.f);
                                 const int hb = (inT & (low ^ 1)) ? bin : 0;
-                                const uint32_t inc = (uint32_t)(inT & (low ^ 1)) << ((hb & 3) * 8);
-                                atomicAdd(&L.hist[(uint32_t)(hb >> 2) * LANES + histBase], inc);
+                                const uint32_t inc = (uint32_t)(inT & (low ^ 1)) << ((hb & 7) * 4);
+                                atomicAdd(&L.hist[(uint32_t)(hb >> 3) * LANES + histBase], inc);
                             }
                         }
                         bool ok = need && cnt >= k && below < k;
@@ -383,20 +391,21 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         const bool shortSet = need && fullR && cnt < k && cnt < 250;
                         if (STATS) { wc.diag0 += __popcll(__ballot(need && cnt < k && !shortSet)); wc.diag1 += __popcll(__ballot(need && cnt >= k && below >= k)); }
                         int bstar = -1, cumBelow = 0, binCount = 0;
+                        int cumAll = below;
                         {
-                            int cum = below;
 #pragma unroll
-                            for (int wd = 0; wd < GRP_BINS / 4; ++wd) {
+                            for (int wd = 0; wd < GRP_BINS / 8; ++wd) {
                                 const uint32_t word = L.hist[wd * LANES + lane];
 #pragma unroll
-                                for (int s = 0; s < 4; ++s) {
-                                    const int cb = (int)((word >> (8 * s)) & 255u);
-                                    if (bstar < 0 && cum + cb >= k) { bstar = 4 * wd + s; cumBelow = cum; binCount = cb; }
-                                    cum += cb;
+                                for (int s = 0; s < 8; ++s) {
+                                    const int cb = (int)((word >> (4 * s)) & 15u);
+                                    if (bstar < 0 && cumAll + cb >= k) { bstar = 8 * wd + s; cumBelow = cumAll; binCount = cb; }
+                                    cumAll += cb;
                                 }
                             }
                         }
-                        ok = ok && bstar >= 0 && binCount <= GRP_MINI && cnt < 250;   // byte counters never wrapped: every bin <= cnt < 256
+                        // a 4-bit counter that wrapped (> 15 values in one bin) makes the counters' total fall short of cnt: not trusted
+                        ok = ok && bstar >= 0 && binCount <= GRP_MINI && cumAll == cnt;
                         // ---- pass 2: (a) the values of bin bstar go to the lane's mini list; (b) every bucket photon that can
                         // belong to SOME lane's k-NN set (it lies in a bin <= that lane's bstar) goes to the compact list, in bucket order
                         int nb = 0, nC = 0;
@@ -622,7 +631,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;   // the fallback candidate arrays alias the bucket
-    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 4) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 2) * 2;
+    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 2) * 2;
 }
 
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {

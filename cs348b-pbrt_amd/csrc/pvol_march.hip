@@ -35,6 +35,9 @@
 #define PAINT_ROW 16   // rows up to this many photons go through the painted index list
 #define PAINT_CAP (64 * PAINT_ROW)
 #ifndef PVOL_WPE
+#ifndef PVOL_WPE_BIG
+#define PVOL_WPE_BIG 2   // k > 64 instantiations (NREG 12): 2 waves/SIMD measured best on a C3-like load (0.129 vs 0.124 at 1, 0.079 Msamples/s at 3)
+#endif
 #define PVOL_WPE 3   // minimum waves per SIMD the register allocator must leave room for (3 measured best: profiles/)
 #endif
 
@@ -49,26 +52,24 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b) {
     uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-// core/rng.cpp:80-92, 64 words per step.  Within a step every lane reads before any lane writes (LDS
-// operations of one wave execute in order), so "old" and "new" words are exactly the serial loop's.
+// core/rng.cpp:80-92, 64 words per step.  Every kernel that owns an MT19937 state runs ONE wave per workgroup, and
+// the LDS operations of a wave execute in program order: within a step all lanes read before any lane writes (one
+// load instruction, then one store instruction), and a later step's reads see the earlier steps' writes -- exactly the
+// "old" and "new" words of the serial loop, without barriers (they cost ~4x in this latency-bound routine).
 __device__ void mt_regenerate(uint32_t *mt, int lane) {
     for (int base = 0; base < MT_N - MT_M; base += LANES) {
         int kk = base + lane;
-        uint32_t v = 0;
-        bool on = kk < MT_N - MT_M;
-        if (on) v = mt[kk + MT_M] ^ mt_twist(mt[kk], mt[kk + 1]);
-        __syncthreads();
-        if (on) mt[kk] = v;
-        __syncthreads();
+        if (kk < MT_N - MT_M) {
+            uint32_t v = mt[kk + MT_M] ^ mt_twist(mt[kk], mt[kk + 1]);
+            mt[kk] = v;
+        }
     }
     for (int base = MT_N - MT_M; base < MT_N - 1; base += LANES) {
         int kk = base + lane;
-        uint32_t v = 0;
-        bool on = kk < MT_N - 1;
-        if (on) v = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1]);
-        __syncthreads();
-        if (on) mt[kk] = v;
-        __syncthreads();
+        if (kk < MT_N - 1) {
+            uint32_t v = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1]);
+            mt[kk] = v;
+        }
     }
     if (lane == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_twist(mt[MT_N - 1], mt[0]);
     __syncthreads();
@@ -956,7 +957,7 @@ __device__ __forceinline__ void flush_counters(DevCounters *c, const WaveCounter
 
 // LDS plan (bytes): [MT 2496 (SEQ)] | cand d2 cap*4 | cand idx cap*4 | lightNum maxSteps*4 (SEQ) | prevRk PREV_N*4 | paint PAINT_CAP*4
 template <bool STATS, int NREG>
-__global__ __launch_bounds__(LANES, PVOL_WPE) void li_seq_kernel(LiArgs A) {
+__global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void li_seq_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
@@ -1028,7 +1029,7 @@ __global__ void stream_begin_kernel(pvol_stream *st, uint32_t n) {
 }
 
 template <bool STATS, int NREG>
-__global__ __launch_bounds__(LANES, PVOL_WPE) void li_par_kernel(LiArgs A) {
+__global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void li_par_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
@@ -1142,7 +1143,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_resolve_kernel(LiArgs A) {
 
 // Heavy pass of slice sliceK: one wave per ray, chunk c = 64 consecutive rays of one stream's slice.
 template <bool STATS, int NREG>
-__global__ __launch_bounds__(LANES, PVOL_WPE) void li_replay_kernel(LiArgs A) {
+__global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void li_replay_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;

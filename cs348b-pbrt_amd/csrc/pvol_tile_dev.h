@@ -50,13 +50,22 @@ __device__ void tile_shuffle(float *samp, uint32_t count, uint32_t dims, uint32_
         if (lane < cnt) oth[i] = i + (r % (count - i));
     }
     __syncthreads();
-    if (lane == 0) {
+    if (lane == 0) {   // the swaps depend on each other through the array: one lane, next index fetched a step ahead
+        uint32_t oNext = oth[0];
         for (uint32_t i = 0; i < count; ++i) {
-            const uint32_t o = oth[i];
-            for (uint32_t j = 0; j < dims; ++j) {
-                float a = samp[dims * i + j], b = samp[dims * o + j];
-                samp[dims * i + j] = b;
-                samp[dims * o + j] = a;
+            const uint32_t o = oNext;
+            if (i + 1 < count) oNext = oth[i + 1];
+            if (dims == 2) {
+                float2 *s2 = reinterpret_cast<float2 *>(samp);
+                const float2 a = s2[i], b = s2[o];
+                s2[i] = b;
+                s2[o] = a;
+            } else {
+                for (uint32_t j = 0; j < dims; ++j) {
+                    float a = samp[dims * i + j], b = samp[dims * o + j];
+                    samp[dims * i + j] = b;
+                    samp[dims * o + j] = a;
+                }
             }
         }
     }
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
     M.lightNum = reinterpret_cast<float *>(lds + MT_N * 4);
     M.prevRk = 0;
     TileLds L;
-    L.image = M.lightNum + (FUSED ? S.maxSteps : 0);
+    L.image = M.lightNum + (FUSED ? ((S.maxSteps + 1) & ~1) : 0);   // 8-byte aligned: the image samples are swapped as float2
     L.time = L.image + 2 * T.spp;
     L.scatter = L.time + T.spp;
     L.oth = reinterpret_cast<uint32_t *>(L.scatter + T.spp);
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
 }
 
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused) {
-    return (size_t)MT_N * 4 + (fused ? (size_t)maxSteps * 4 : 0) + (size_t)spp * 5 * 4;
+    return (size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4;
 }
 
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream) {

@@ -94,3 +94,15 @@ def test_product_does_not_touch_the_oracle():
                     if re.search(r"\boracle/|liborc|\borc_|import orc", t):
                         bad.append(os.path.join(dp, f))
     assert bad == [], bad
+
+
+def test_host_helpers_of_the_tile_driver_match_the_reference_capture(pvol):
+    """pvol_gaussian_filter_table / pvol_compute_sub_window / pvol_render_sample_count need no GPU: checked against the
+    values the reference's ImageFilm, GaussianFilter and Sampler::ComputeSubWindow produced (tests/golden/render_vh.bin)."""
+    import numpy as np
+    from conftest import load_render_case
+    s, p, cam, film, smp, c = load_render_case("vh")
+    np.testing.assert_array_equal(pvol.gaussian_filter_table(2.0, 2.0, 2.0), c["film.filter_table"])
+    for i, t in enumerate(c["tasks"]):
+        assert pvol.sub_window(smp, int(t)) == list(c["task.window"][4 * i:4 * i + 4])
+    assert pvol.render_sample_count(smp, c["tasks"]) == int(c["task.n_samples"].sum()) == len(c["samples.time"])

@@ -88,7 +88,7 @@ def run(name, scene_name, xres, yres, spp, n_photons, tasks, note, **over):
 if __name__ == "__main__":
     run("C1-h", "volumescene_h", 256, 256, 16, 100000, 4096, "config 1 with Volume homogeneous (gather on)")
     run("C1-literal", "volumescene_rainbow", 256, 256, 16, 100000, 4096, "config 1 as shipped (rainbow volume: no gather)")
-    run("C3", "pinkfloyd", 480, 270, 4, 4000000, 1024, "config 3 at 1/16 resolution, 4 spp instead of 512, 1 GPU; two lights => stream-sequential kernel",
+    run("C3", "pinkfloyd", 480, 270, 4, 4000000, 1024, "config 3 at 1/16 resolution, 4 spp instead of 512, 1 GPU; two lights => resolve/replay kernels",
         n_caustic_photons=0)
     run("C4", "volumescene_grid16", 128, 128, 8, 2000000, 16384, "config 4: 128^3 VolumeGrid regenerated here, 128x128 at 8 spp instead of 256^2 at 1024",
         density_n=128)

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     // mean at this step; the full radius when neither exists.  The bucket covers the largest of them.
                     float gbl = lastRk;
                     if (j < PREV_N) gbl = fmaxf(gbl, M.prevRk[j]);
-                    float Tl = (gbl > 0.f && gbl * PVOL_GUESS_SCALE < S.maxDistSq) ? gbl * PVOL_GUESS_SCALE : S.maxDistSq;
+                    float Tl = (gbl > 0.f && gbl * A.grpGuess < S.maxDistSq) ? gbl * A.grpGuess : S.maxDistSq;
                     bool fullR = !(Tl < S.maxDistSq);
                     float T = need ? Tl : 0.f;
                     T = wave_max(T);

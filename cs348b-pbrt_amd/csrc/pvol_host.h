@@ -26,6 +26,7 @@ struct LiArgs {
     unsigned char *records;
     uint32_t recStride, sliceM, sliceK;
     uint32_t *state;
+    float grpGuess;
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;

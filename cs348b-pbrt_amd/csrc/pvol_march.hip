@@ -409,6 +409,7 @@ struct LiArgs {
     unsigned char *records;     // [nStreams * sliceM] slots of recStride bytes
     uint32_t recStride, sliceM, sliceK;
     uint32_t *state;            // [nStreams][625]
+    float grpGuess;             // li_group_kernel: search radius^2 = this x the guessed k-th distance^2
 };
 
 // PhotonVolumeIntegrator::Transmittance with sample == NULL (photonvolume.cpp:15-30)

@@ -88,8 +88,10 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
 
     const uint32_t T = n_tasks;
     const uint32_t blockSize = 4096;
-    // room for one block of one task: spectral splitting stores up to ~3 photons per path
-    const uint32_t cap = 16384;
+    // room for one block of one task: spectral splitting stores up to ~3 photons per path.  With very many
+    // virtual tasks (one lane each: the way to fill the chip) the per-task room shrinks to keep the pool within 48 GB;
+    // a task that outgrows it fails the call with PVOL_E_LIMIT rather than dropping photons.
+    const uint32_t cap = (uint32_t)std::min<size_t>(16384, std::max<size_t>(1024, ((size_t)48 << 30) / ((size_t)T * 144)));
     Buffers B;
     bool good = ok(hipMalloc(&B.mt, sizeof(uint32_t) * 625 * (size_t)T)) && ok(hipMalloc(&B.halton, sizeof(uint32_t) * 41 * (size_t)T)) &&
                 ok(hipMalloc(&B.totalPaths, sizeof(uint32_t) * T)) && ok(hipMalloc(&B.flags, sizeof(uint32_t) * T)) &&

@@ -406,7 +406,9 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     a.out = dOut; a.draws = dDraws; a.initState = dInit; a.finalState = dFinal; a.counters = c->dCounters;
     a.transmittanceOnly = transOnly;
     a.chunkCounter = c->dWords; a.needSeq = c->dWords + 1; a.gated = 0;
-    { const char *gs = getenv("PVOL_GROUP_GUESS"); a.grpGuess = gs ? (float)atof(gs) : 1.15f; if (!(a.grpGuess >= 1.f)) a.grpGuess = 1.15f;   // measured: 1.3 -> 55.5, 1.2 -> 57.5, 1.12 -> 58.0, 1.06 -> 56.6, 1.0 -> 51.0 Msamples/s at 64 spp }
+    // li_group_kernel bucket radius^2 = this x the guessed k-th distance^2 (measured at 64 spp: 1.3 55.5, 1.2 57.5, 1.12 58.0,
+    // 1.06 56.6, 1.0 51.0 Msamples/s)
+    { const char *gs = getenv("PVOL_GROUP_GUESS"); a.grpGuess = gs ? (float)atof(gs) : 1.15f; if (!(a.grpGuess >= 1.f)) a.grpGuess = 1.15f; }
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
         std::lock_guard<std::mutex> g(c->mu);

@@ -264,13 +264,25 @@ __device__ f4 vol_tau(const DevScene &S, const RayD &r, float stepSize, float u,
     RayD rn;
     rn.o = r.o; rn.d = vdiv(r.d, length); rn.mint = r.mint * length; rn.maxt = r.maxt * length;
     if (!vol_intersect(S, rn, &t0, &t1)) return mk4(0.f);
-    f4 tau = mk4(0.f);
+    // DensityRegion::tau (core/volume.cpp:296-310): tau += sigma_t(p(t0)) per sample, t0 += stepSize.  The ray is
+    // wave-uniform, so the samples go one per lane: the t0 sequence is replayed with the reference's additions (cheap,
+    // serial), the trilinear density fetches run in parallel, and sigma_t (constant times density, volume.h:81-92)
+    // multiplies the summed densities once -- the only difference is the order of that sum.
+    const int lane = (int)threadIdx.x & (LANES - 1);
+    float dsum = 0.f;
     t0 += u * stepSize;
     while (t0 < t1) {
-        tau = tau + sigT * vol_density(S, rn.o + rn.d * t0);
-        t0 += stepSize;
+        float tMine = 0.f;
+        bool mine = false;
+        for (int j = 0; j < LANES && t0 < t1; ++j) {
+            if (lane == j) { tMine = t0; mine = true; }
+            t0 += stepSize;
+        }
+        float dl = mine ? vol_density(S, rn.o + rn.d * tMine) : 0.f;
+        for (int off = 32; off > 0; off >>= 1) dl += __shfl_xor(dl, off);
+        dsum += dl;
     }
-    return tau * stepSize;
+    return sigT * dsum * stepSize;
 }
 
 // volumes/rainbow.cpp:41-78 in the float4 layout

@@ -620,7 +620,7 @@ int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
     out->n_rays = h.nRays; out->n_steps = h.nSteps; out->n_tested = h.nTested; out->n_kept = h.nKept;
     out->n_lookups_lt10 = h.nLookupsLt10; out->n_shadow_unoccluded = h.nShadowUnoccluded;
     out->n_guess_retries = h.pad;
-    out->reserved[0] = h.diag[0]; out->reserved[1] = h.diag[1]; out->reserved[2] = h.diag[2];
+    out->group_guess_failed = h.diag[0]; out->group_plan_skipped = h.diag[1]; out->cy_fallback = h.diag[2];
     out->cy_search = h.cySearch; out->cy_select = h.cySelect; out->cy_flux = h.cyFlux; out->cy_total = h.cyTotal;
     if (reset && !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) return PVOL_E_NO_DEVICE;
     return PVOL_OK;

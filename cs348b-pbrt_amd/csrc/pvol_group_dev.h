@@ -307,7 +307,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         ++uCount;
                     }
                 }
-                if (STATS) { wc.steps += __popcll(__ballot(act)); }
+                if (STATS) { wc.steps += __popcll(__ballot(act)); wc.unocc += __popcll(__ballot(lit)); }
                 // ---- k-NN gather of the group
                 float acc[32];
 #pragma unroll
@@ -348,9 +348,9 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             Tl = fminf(S.maxDistSq, fmaxf(Tl, fminf(cover * cover, gbl * GRP_WIDEN)));
                             fullR = !(Tl < S.maxDistSq);
                         }
-                        if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; wc.lt10 += 1; }
+                        if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; }
                     }
-                    if (STATS && Mb < 0) wc.diag2 += __popcll(needMask);
+                    if (STATS && Mb < 0) wc.diag1 += __popcll(needMask);   // bucket plan skipped (overflow, k out of range)
                     if (Mb >= 0) {
                         const unsigned long long tp1 = STATS ? stamp() : 0ull;
                         typedef float nf4 __attribute__((ext_vector_type(4)));
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         bool ok = need && cnt >= k && below < k;
                         // the full radius holds fewer than k photons: all of them count, r^2 = the farthest (photonvolume.cpp:76-105)
                         const bool shortSet = need && fullR && cnt < k && cnt < 250;
-                        if (STATS) { wc.diag0 += __popcll(__ballot(need && cnt < k && !shortSet)); wc.diag1 += __popcll(__ballot(need && cnt >= k && below >= k)); }
+                        if (STATS) wc.diag0 += __popcll(__ballot(need && ((cnt < k && !shortSet) || (cnt >= k && below >= k))));   // radius guess too small / too large
                         int bstar = -1, cumBelow = 0, binCount = 0;
                         int cumAll = below;
                         {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         }
 #undef GRP_D2X4
                         if (ok) { done = true; viaPlan = true; if (shortSet) nFoundLane = cnt; }
-                        if (STATS) { wc.kept += (unsigned long long)__popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
+                        if (STATS) { wc.kept += (unsigned long long)k * __popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
                     }
                     // ---- lanes the plan did not serve: the wave-cooperative exact lookup, one lane at a time
                     uint64_t todo = __ballot(need && !done);
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         }
                         if (lane == l) rk = rkl;
                     }
-                    if (STATS) { wc = wsave; wc.retries += nfb; wc.unocc += stamp() - tfb; }   // diagnostic build: n_guess_retries = fallback lookups, n_shadow_unoccluded = their cycles
+                    if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
                     const float rkGuess = (need && nFoundLane >= k) ? rk : 0.f;   // as lphoton's rkOut: a k-th distance exists only for full sets
                     {   // mean k-th distance^2 of the group at this step -> guess of the next group
                         float sr = rkGuess, sn = rkGuess > 0.f ? 1.f : 0.f;

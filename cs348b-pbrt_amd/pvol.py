@@ -200,9 +200,7 @@ class PhotonVolume:
     def stats(self, reset=False):
         s = abi.Stats()
         _check(lib().pvol_get_stats(self._h, C.byref(s), int(reset)), "pvol_get_stats")
-        d = {k: int(getattr(s, k)) for k, _ in abi.Stats._fields_ if k != "reserved"}
-        d["group_guess_short"], d["group_guess_long"], d["group_plan_skipped"] = (int(v) for v in s.reserved)
-        return d
+        return {k: int(getattr(s, k)) for k, _ in abi.Stats._fields_}
 
     def march_kernel_name(self):
         return lib().pvol_march_kernel_name(self._h).decode()

@@ -170,12 +170,14 @@ typedef struct pvol_stats {
     uint64_t n_kept;           /* photons that entered a flux sum                         */
     uint64_t n_lookups_lt10;   /* lookups that found < 10 photons (photonvolume.cpp:83)   */
     uint64_t n_shadow_unoccluded;
-    uint64_t n_guess_retries;  /* lookups whose predicted radius held < k photons and were redone at maxdist */
+    uint64_t n_guess_retries;  /* lookups redone exactly: predicted radius held < k photons (lphoton), or not served by the bucket plan (group kernel) */
     uint64_t cy_search;        /* s_memtime cycles summed over wavefronts: candidate search ...          */
     uint64_t cy_select;        /* ... k-selection ...                                                     */
     uint64_t cy_flux;          /* ... flux sum ...                                                        */
     uint64_t cy_total;         /* ... whole kernel                                                        */
-    uint64_t reserved[3];
+    uint64_t group_guess_failed;  /* li_group_kernel: lookups whose guessed search radius was too small or too large ...   */
+    uint64_t group_plan_skipped;  /* ... whose shared photon bucket overflowed (or k outside the plan) ...                 */
+    uint64_t cy_fallback;         /* ... and the cycles of the exact wave-cooperative lookups that served both (n_guess_retries counts them) */
 } pvol_stats;
 
 /* ---- tile driver, SURVEY 8(f)-1: the caller of Li() (LD sampler, perspective camera) and its

@@ -78,6 +78,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     c->nCU = 256;
     { const char *fs = getenv("PVOL_FORCE_SEQ"); c->forceSeq = fs && fs[0] == '1'; }
     { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
+    { const char *nl = getenv("PVOL_NO_LITE"); c->noLite = nl && nl[0] == '1'; }
     { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 8; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
@@ -238,6 +239,9 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         size_t nb = sizeof(float) * (size_t)v.nx * v.ny * v.nz;
         if (!ok(hipMalloc(&c->dDensity, nb))) return PVOL_E_NO_MEMORY;
         if (!ok(hipMemcpy(c->dDensity, v.density, nb, hipMemcpyHostToDevice))) return PVOL_E_NO_DEVICE;
+        float md = 0.f;
+        for (size_t i = 0; i < nb / sizeof(float); ++i) md = std::max(md, v.density[i]);
+        c->maxDensity = md;
         h.density = c->dDensity;
     }
     h.nLights = (int)s->n_lights;
@@ -392,7 +396,10 @@ static int launch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_strea
 static bool roulette_possible(const pvol_ctx *c) {
     float m = 0.f;
     for (int i = 0; i < PVOL_NBINS; ++i) m = std::max(m, c->hs.sigA[i] + c->hs.sigS[i]);
-    return !(c->hs.stepSize * m < 6.8f);
+    // VolumeGrid: trilinear interpolation never exceeds the grid maximum, and the stepped tau() of a segment (samples every
+    // stepSize/2, DensityRegion::tau) can overshoot the segment by one sample: 1.5 x stepSize bounds it
+    const float dens = c->hs.volKind == PVOL_VOLUME_GRID ? 1.5f * c->maxDensity : 1.f;
+    return !(c->hs.stepSize * m * dens < 6.8f);
 }
 
 // `tile` != 0: the rays do not exist yet -- the tile kernel (pvol_tile_dev.h) generates them stream by stream
@@ -451,6 +458,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         if (stBytes > c->stateBytes) { if (c->dState) hipFree(c->dState); c->dState = 0; c->stateBytes = 0;
                                        if (!ok(hipMalloc(&c->dState, stBytes))) return PVOL_E_NO_MEMORY; c->stateBytes = stBytes; }
         a.records = c->dRecords; a.recStride = (uint32_t)stride; a.sliceM = sliceM; a.state = c->dState;
+        a.liteResolve = (!tile && !c->noLite && !roulette_possible(c)) ? 1 : 0;
     }
     if (par) hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
     if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel

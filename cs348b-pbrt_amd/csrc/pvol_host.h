@@ -27,6 +27,7 @@ struct LiArgs {
     uint32_t recStride, sliceM, sliceK;
     uint32_t *state;
     float grpGuess;
+    int liteResolve;
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
@@ -63,6 +64,8 @@ struct pvol_ctx {
     DevCounters *dCounters;
     uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
     int nCU;
+    float maxDensity = 1.f;   // largest density factor of the medium (1 for analytic volumes, max of the grid values)
+    bool noLite = false;      // PVOL_NO_LITE=1: keep the geometry inside the sequential resolve pass (testing)
     const char *lastKernel = "";
     int groupWavesPerCU; // resident li_group_kernel waves per CU (LDS plan: 8); PVOL_GROUP_WAVES overrides
     bool noGroup;       // PVOL_NO_GROUP=1: keep li_par_kernel (one wave per ray) where li_group_kernel (one ray per lane) would run

@@ -410,6 +410,7 @@ struct LiArgs {
     uint32_t recStride, sliceM, sliceK;
     uint32_t *state;            // [nStreams][625]
     float grpGuess;             // li_group_kernel: search radius^2 = this x the guessed k-th distance^2
+    int liteResolve;            // no march step can reach the roulette: geometry pre-pass + RNG-only resolve
 };
 
 // PhotonVolumeIntegrator::Transmittance with sample == NULL (photonvolume.cpp:15-30)
@@ -1192,6 +1193,184 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
 
+// ------------------------------------------------------------------------------------------ geometry pre-pass + lite resolve
+// When no march step can reach the Russian roulette (decided on the host from stepSize * max sigma_t * max density), the
+// only things the RNG pre-pass needs from a ray's geometry are the step count n and, per step, which lights would be
+// sampled unoccluded -- none of it depends on drawn values.  li_geo_kernel computes them ray-parallel (one wave per ray,
+// one march step per lane) into the record slots; li_resolve_lite_kernel then walks each stream's rays in order touching
+// only the MT19937 state: LDShuffleScrambled1D for lightNum, one draw per step, one per unoccluded sample (A.1).
+template <int NREG>
+__global__ __launch_bounds__(LANES) void li_geo_kernel(LiArgs A) {
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    const int q = lane & 7;
+    const bool grid = (S.volKind == PVOL_VOLUME_GRID);
+    const f4 sigS = ld4(S.sigS, q);
+    const bool blackS1 = spec_is_black(sigS);
+    unsigned int lightBlackMask = 0u;
+    for (int l = 0; l < S.nLights; ++l) if (spec_is_black(ld4(S.lights[l].intensity, q))) lightBlackMask |= 1u << l;
+    const uint32_t chunksPerSlice = (A.sliceM + CHUNK_RAYS - 1) / CHUNK_RAYS;
+    const unsigned long long nChunks = (unsigned long long)chunksPerSlice * A.nStreams;
+    for (unsigned long long chunk = blockIdx.x; chunk < nChunks; chunk += gridDim.x) {
+        const uint32_t sidx = (uint32_t)(chunk / chunksPerSlice), jc = (uint32_t)(chunk - (unsigned long long)sidx * chunksPerSlice);
+        const uint32_t nr = A.streams[sidx].n_rays, first = A.streams[sidx].first_ray;
+        const uint32_t begin = A.sliceK * A.sliceM;
+        if (begin >= nr) continue;
+        const uint32_t sliceLen = min(nr - begin, A.sliceM);
+        const uint32_t l0 = jc * CHUNK_RAYS;
+        if (l0 >= sliceLen) continue;
+        const uint32_t l1 = min(sliceLen, l0 + CHUNK_RAYS);
+        for (uint32_t l = l0; l < l1; ++l) {
+            const pvol_ray pr = A.rays[(size_t)first + begin + l];
+            RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + l) * A.recStride, S.maxSteps, grid);
+            RayD ray;
+            ray.o = v3(pr.o[0], pr.o[1], pr.o[2]); ray.d = v3(pr.d[0], pr.d[1], pr.d[2]); ray.mint = pr.mint; ray.maxt = pr.maxt;
+            float t0, t1;
+            bool hit = S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
+            int nSamples = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
+            if (hit && nSamples > S.maxSteps) {   // the record plan cannot hold this ray: report, never guess
+                if (lane == 0) atomicAdd(&A.counters->nErrors, 1ull);
+                nSamples = 0;
+            }
+            if (lane == 0) { rec.hdr[0] = (uint32_t)nSamples; rec.hdr[1] = 0u; }
+            if (nSamples == 0) continue;
+            const float step = (t1 - t0) / nSamples;
+            float tcur = t0 + pr.scatter_u * step;
+            for (int base = 0; base < nSamples; base += LANES) {
+                const int cnt = min(LANES, nSamples - base);
+                float tMine = 0.f;
+                for (int j = 0; j < cnt; ++j) {   // t0 is ACCUMULATED in the reference: replay the additions
+                    if (lane == j) tMine = tcur;
+                    tcur += step;
+                }
+                const bool on = lane < cnt;
+                const V3 p = ray.o + ray.d * tMine;
+                const V3 pv = xform_point(S.w2v, p);
+                const float dens = !on ? 0.f : (grid ? grid_density(S, pv) : (box_inside(S.extLo, S.extHi, pv) ? 1.f : 0.f));
+                unsigned int mask = 0u;
+                if (on && dens != 0.f && !blackS1 && S.nLights > 0) {   // sigma_s * dens is black iff dens == 0 or sigma_s is
+                    mask = 0x80u;
+                    for (int ln = 0; ln < S.nLights; ++ln) {
+                        const DevLight &light = S.lights[ln];
+                        RayD vis;
+                        float fall = 1.f;
+                        if (light.kind == PVOL_LIGHT_DISTANT) {
+                            vis.o = p; vis.d = v3(light.dir[0], light.dir[1], light.dir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
+                        } else {
+                            V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
+                            V3 wo = normalize(lp - p);
+                            float dist = len(p - lp);
+                            vis.o = p; vis.d = vdiv(lp - p, dist); vis.mint = 0.f; vis.maxt = dist * (1.f - 0.f);
+                            if (light.kind == PVOL_LIGHT_SPOT) {
+                                V3 wl = normalize(v3(light.w2l[0] * -wo.x + light.w2l[1] * -wo.y + light.w2l[2] * -wo.z,
+                                                     light.w2l[4] * -wo.x + light.w2l[5] * -wo.y + light.w2l[6] * -wo.z,
+                                                     light.w2l[8] * -wo.x + light.w2l[9] * -wo.y + light.w2l[10] * -wo.z));
+                                float costheta = wl.z;
+                                if (costheta < light.cosTotalWidth) fall = 0.f;
+                                else if (costheta > light.cosFalloffStart) fall = 1.f;
+                                else {
+                                    float delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+                                    fall = delta * delta * delta * delta;
+                                }
+                            }
+                        }
+                        const bool black = (fall == 0.f) || ((lightBlackMask >> ln) & 1u);
+                        if (!black && !lane_occluded(S, vis)) mask |= 1u << ln;
+                    }
+                }
+                if (on) rec.stepByte[base + lane] = (unsigned char)mask;
+            }
+        }
+    }
+}
+
+template <int NREG>
+__global__ __launch_bounds__(LANES) void li_resolve_lite_kernel(LiArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    const uint32_t sidx = blockIdx.x;
+    if (sidx >= A.nStreams) return;
+    uint32_t *mt = reinterpret_cast<uint32_t *>(lds);
+    float *lightNum = reinterpret_cast<float *>(lds + MT_N * 4);
+    pvol_stream st = A.streams[sidx];
+    const uint32_t begin = A.sliceK * A.sliceM;
+    if (begin >= st.n_rays && !(A.sliceK == 0)) return;
+    Rng rng;
+    rng.mt = mt;
+    rng.draws = 0;
+    uint32_t *state = A.state + (size_t)sidx * (MT_N + 1);
+    if (A.sliceK == 0 && !A.initState) {
+        mt_seed(mt, st.seed, lane);
+        rng.mti = MT_N;
+        rng_skip<true>(rng, st.start_draw, lane);
+    } else {
+        const uint32_t *src = (A.sliceK == 0) ? A.initState + (size_t)sidx * (MT_N + 1) : state;
+        for (int i = lane; i < MT_N; i += LANES) mt[i] = src[i];
+        rng.mti = (int)src[MT_N];
+        rng.draws = (A.sliceK == 0) ? st.start_draw : st.end_draw;
+        __syncthreads();
+    }
+    const bool grid = (S.volKind == PVOL_VOLUME_GRID);
+    const int nLights = S.nLights;
+    const uint32_t end = min(st.n_rays, begin + A.sliceM);
+    for (uint32_t k = begin; k < end; ++k) {
+        const size_t ri = (size_t)st.first_ray + k;
+        rng_skip<true>(rng, A.rays[ri].rng_skip, lane);
+        const unsigned long long d0 = rng.draws;
+        RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k - begin)) * A.recStride, S.maxSteps, grid);
+        const int n = (int)rec.hdr[0];
+        if (n > 0) {
+            // LDShuffleScrambled1D(1, n, lightNum) + (1, n, lightComp) + 2D(1, n, lightPos): 4 + 6n draws (photonvolume.cpp:137-142)
+            if (nLights > 1) {
+                const uint32_t scramble = rng_uint<true>(rng, lane);
+                for (int i = lane; i < n; i += LANES) lightNum[i] = van_der_corput((uint32_t)i, scramble);
+                rng_skip<true>(rng, (unsigned long long)n, lane);
+                __syncthreads();
+                for (int i = 0; i < n; ++i) {   // Shuffle(samples, n, 1), montecarlo.h:174-181
+                    const uint32_t other = (uint32_t)i + (rng_uint<true>(rng, lane) % (uint32_t)(n - i));
+                    if (lane == 0) {
+                        const float a = lightNum[i], b = lightNum[other];
+                        lightNum[i] = b;
+                        lightNum[other] = a;
+                    }
+                }
+                __syncthreads();
+                rng_skip<true>(rng, 3ull + 4ull * (unsigned long long)n, lane);
+            } else {
+                rng_skip<true>(rng, 4ull + 6ull * (unsigned long long)n, lane);
+            }
+            for (int i = 0; i < n; ++i) {
+                const float uTau = rng_float<true>(rng, lane);
+                const unsigned int mask = rec.stepByte[i];
+                unsigned int outByte = 0u;
+                float uSh = 0.f;
+                if (mask & 0x80u) {
+                    int ln = 0;
+                    if (nLights > 1) ln = min((int)floorf(lightNum[i] * nLights), nLights - 1);
+                    outByte = (unsigned int)ln;
+                    if ((mask >> ln) & 1u) uSh = rng_float<true>(rng, lane);
+                }
+                if (lane == 0) {
+                    rec.stepByte[i] = (unsigned char)outByte;
+                    if (grid) { rec.stepU[2 * i] = uTau; rec.stepU[2 * i + 1] = uSh; }
+                }
+            }
+        }
+        if (lane == 0) rec.hdr[2] = (uint32_t)(rng.draws - d0);
+        if (A.draws && lane == 0) A.draws[ri] = (uint32_t)(rng.draws - d0);
+    }
+    if (lane == 0) A.streams[sidx].end_draw = rng.draws;
+    __syncthreads();
+    for (int i = lane; i < MT_N; i += LANES) state[i] = mt[i];
+    if (lane == 0) state[MT_N] = (uint32_t)rng.mti;
+    if (A.finalState && end >= st.n_rays) {
+        uint32_t *dst = A.finalState + (size_t)sidx * (MT_N + 1);
+        for (int i = lane; i < MT_N; i += LANES) dst[i] = mt[i];
+        if (lane == 0) dst[MT_N] = (uint32_t)rng.mti;
+    }
+}
+
 extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream) {
     dim3 grid(args->nStreams), block(LANES);
     // NREG = candidate registers per lane in select_k: 4 covers nused <= 64, 12 covers nused <= 576
@@ -1222,6 +1401,11 @@ extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, in
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
                                            uint32_t nWaves, hipStream_t stream, bool resolve) {
     dim3 block(LANES);
+    if (resolve && args->liteResolve) {   // geometry pre-pass (ray-parallel) + RNG-only sequential pass
+        hipLaunchKernelGGL((li_geo_kernel<4>), dim3(nWaves), block, 0, stream, *args);
+        hipLaunchKernelGGL((li_resolve_lite_kernel<4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+        resolve = false;
+    }
     if (candCap <= 4 * LANES) {
         if (resolve) hipLaunchKernelGGL((li_resolve_kernel<false, 4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
         if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 4>), dim3(nWaves), block, ldsReplay, stream, *args);

@@ -108,6 +108,7 @@ struct TileArgs {
     const int4 *windows;           // per stream of the batch: x0, x1, y0, y1 (Sampler::ComputeSubWindow)
     pvol_ray *rays;                // out: camera rays, stream-major, pixel-major, sample-minor
     float *xy;                     // out: imageX, imageY per ray
+    uint32_t debugSkip;            // timing experiments only (PVOL_TILE_DEBUG): 1 skip the swaps, 2 skip the draw count, 4 skip advancing the stream
 };
 
 #endif

@@ -158,8 +158,7 @@ __device__ __forceinline__ bool vol_intersect(const DevScene &S, const RayD &r, 
     return box_intersect(S.extLo, S.extHi, o, d, r.mint, r.maxt, t0, t1);
 }
 // shapes/trianglemesh.cpp:211-243 (any hit) for one triangle
-__device__ __forceinline__ bool tri_hit(const DevTri &tr, const RayD &ray) {
-    V3 p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]), p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+__device__ __forceinline__ bool tri_hit_v(V3 p1, V3 p2, V3 p3, const RayD &ray) {
     V3 e1 = p2 - p1, e2 = p3 - p1;
     V3 s1 = cross(ray.d, e2);
     float divisor = dot(s1, e1);
@@ -174,6 +173,9 @@ __device__ __forceinline__ bool tri_hit(const DevTri &tr, const RayD &ray) {
     float t = dot(e2, s2) * invDivisor;
     if (t < ray.mint || t > ray.maxt) return false;
     return true;
+}
+__device__ __forceinline__ bool tri_hit(const DevTri &tr, const RayD &ray) {
+    return tri_hit_v(v3(tr.p1[0], tr.p1[1], tr.p1[2]), v3(tr.p2[0], tr.p2[1], tr.p2[2]), v3(tr.p3[0], tr.p3[1], tr.p3[2]), ray);
 }
 // shapes/trianglemesh.cpp:116-160 (closest hit: t reported) for one triangle
 __device__ __forceinline__ bool tri_closest(const DevTri &tr, V3 o, V3 d, float mint, float maxt, float *tHit) {

@@ -42,7 +42,7 @@ __device__ __forceinline__ float sobol2(uint32_t n, uint32_t scramble) {
 
 // Shuffle(samp, count, dims, rng), core/montecarlo.h:174-181: the `other` indices are drawn 64 at a time, the
 // swaps themselves are order-dependent and run on lane 0
-__device__ void tile_shuffle(float *samp, uint32_t count, uint32_t dims, uint32_t *oth, Rng &rng, int lane) {
+__device__ void tile_shuffle(float *samp, uint32_t count, uint32_t dims, uint32_t *oth, Rng &rng, int lane, bool skipSwaps = false) {
     for (uint32_t base = 0; base < count; base += LANES) {
         const int cnt = (int)min((uint32_t)LANES, count - base);
         const uint32_t r = rng_bulk(rng, cnt, lane);
@@ -50,7 +50,7 @@ __device__ void tile_shuffle(float *samp, uint32_t count, uint32_t dims, uint32_
         if (lane < cnt) oth[i] = i + (r % (count - i));
     }
     __syncthreads();
-    if (lane == 0) {   // the swaps depend on each other through the array: one lane, next index fetched a step ahead
+    if (lane == 0 && !skipSwaps) {   // the swaps depend on each other through the array: one lane, next index fetched a step ahead
         uint32_t oNext = oth[0];
         for (uint32_t i = 0; i < count; ++i) {
             const uint32_t o = oNext;
@@ -89,7 +89,7 @@ __device__ void tile_pixel_sample(const TileArgs &T, TileLds &L, Rng &rng, int l
         for (uint32_t i = lane; i < n; i += LANES) { L.image[2 * i] = van_der_corput(i, s0); L.image[2 * i + 1] = sobol2(i, s1); }
         rng_skip<true>(rng, n, lane);
         __syncthreads();
-        tile_shuffle(L.image, n, 2, L.oth, rng, lane);
+        tile_shuffle(L.image, n, 2, L.oth, rng, lane, (T.debugSkip & 1u) != 0u);
     }
     rng_skip<true>(rng, 2ull + 2ull * n, lane);   // lens
     {
@@ -97,7 +97,7 @@ __device__ void tile_pixel_sample(const TileArgs &T, TileLds &L, Rng &rng, int l
         for (uint32_t i = lane; i < n; i += LANES) L.time[i] = van_der_corput(i, s);
         rng_skip<true>(rng, n, lane);
         __syncthreads();
-        tile_shuffle(L.time, n, 1, L.oth, rng, lane);
+        tile_shuffle(L.time, n, 1, L.oth, rng, lane, (T.debugSkip & 1u) != 0u);
     }
     for (uint32_t a = 0; a < T.n1dCount; ++a) {
         if (a == T.scatterIndex) {   // n1d == 1 (checked on the host)
@@ -105,7 +105,7 @@ __device__ void tile_pixel_sample(const TileArgs &T, TileLds &L, Rng &rng, int l
             for (uint32_t i = lane; i < n; i += LANES) L.scatter[i] = van_der_corput(i, s);
             rng_skip<true>(rng, n, lane);
             __syncthreads();
-            tile_shuffle(L.scatter, n, 1, L.oth, rng, lane);
+            tile_shuffle(L.scatter, n, 1, L.oth, rng, lane, (T.debugSkip & 1u) != 0u);
         } else {
             rng_skip<true>(rng, 1ull + (unsigned long long)T.n1d[a] * n + n, lane);
         }
@@ -142,47 +142,77 @@ __device__ __forceinline__ float tile_clip(const DevScene &S, V3 o, V3 d) {
     return mt;
 }
 
+// What the draw count reads of the scene, taken into registers once per kernel: inside the per-step loop a reference to
+// the DevScene in global memory would be re-read every iteration (the loop's control flow keeps the compiler from hoisting
+// the loads), and that latency dominated the pre-pass.
+struct CountConsts {
+    float w2v[16];
+    float lo[3], hi[3];
+    float stepSize;
+    int volKind, nLights, nTris, lightKind;
+    float ldir[3], lpos[3], w2l[9], cosTotalWidth, cosFalloffStart;
+};
+__device__ __forceinline__ CountConsts count_consts(const DevScene &S) {
+    CountConsts C;
+    for (int i = 0; i < 16; ++i) C.w2v[i] = S.w2v[i];
+    for (int i = 0; i < 3; ++i) { C.lo[i] = S.extLo[i]; C.hi[i] = S.extHi[i]; }
+    C.stepSize = S.stepSize; C.volKind = S.volKind; C.nLights = S.nLights; C.nTris = S.nTris;
+    const DevLight &light = S.lights[0];
+    C.lightKind = light.kind;
+    for (int i = 0; i < 3; ++i) { C.ldir[i] = light.dir[i]; C.lpos[i] = light.pos[i]; }
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) C.w2l[3 * r + c] = light.w2l[4 * r + c];
+    C.cosTotalWidth = light.cosTotalWidth; C.cosFalloffStart = light.cosFalloffStart;
+    return C;
+}
+
 // Number of RandomUInt calls of one Li() when no roulette can fire and at most one light exists: 4 + 6n + n + u
 // (photonvolume.cpp:112-222; same per-step tests as march_ray_blocked's scalar phase).  One ray per lane.
-__device__ uint32_t tile_count_draws(const DevScene &S, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack) {
-    RayD ray;
-    ray.o = o; ray.d = d; ray.mint = 0.f; ray.maxt = maxt;
+__device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack) {
     float t0, t1;
-    if (S.volKind == PVOL_VOLUME_NONE || !vol_intersect(S, ray, &t0, &t1) || (t1 - t0) == 0.f) return 0u;
-    const int nSamples = (int)ceilf((t1 - t0) / S.stepSize);
+    // vol_intersect: BBox::IntersectP of the ray taken to volume space (core/geometry.cpp:68-86)
+    if (C.volKind == PVOL_VOLUME_NONE || !box_intersect(C.lo, C.hi, xform_point(C.w2v, o), xform_vector(C.w2v, d), 0.f, maxt, &t0, &t1) || (t1 - t0) == 0.f) return 0u;
+    const int nSamples = (int)ceilf((t1 - t0) / C.stepSize);
     const float step = (t1 - t0) / nSamples;
     float tcur = t0 + scatterU * step;
     uint32_t u = 0;
-    const bool tryLight = !blackS && S.nLights > 0 && !lightBlack;
+    const bool tryLight = !blackS && C.nLights > 0 && !lightBlack;
+    if (!tryLight) return 4u + 7u * (uint32_t)nSamples;
     for (int j = 0; j < nSamples; ++j) {
         const V3 p = o + d * tcur;
         tcur += step;
-        if (!tryLight) continue;
-        if (!box_inside(S.extLo, S.extHi, xform_point(S.w2v, p))) continue;
-        const DevLight &light = S.lights[0];
+        const V3 pv = xform_point(C.w2v, p);
+        if (!box_inside(C.lo, C.hi, pv)) continue;
         RayD vis;
-        if (light.kind == PVOL_LIGHT_DISTANT) {
-            vis.o = p; vis.d = v3(light.dir[0], light.dir[1], light.dir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
+        if (C.lightKind == PVOL_LIGHT_DISTANT) {
+            vis.o = p; vis.d = v3(C.ldir[0], C.ldir[1], C.ldir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
         } else {
-            const V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
+            const V3 lp = v3(C.lpos[0], C.lpos[1], C.lpos[2]);
             const V3 wo = normalize(lp - p);
             const float dist = len(p - lp);
             vis.o = p; vis.d = vdiv(lp - p, dist); vis.mint = 0.f; vis.maxt = dist * (1.f - 0.f);
-            if (light.kind == PVOL_LIGHT_SPOT) {
-                V3 wl = normalize(v3(light.w2l[0] * -wo.x + light.w2l[1] * -wo.y + light.w2l[2] * -wo.z,
-                                     light.w2l[4] * -wo.x + light.w2l[5] * -wo.y + light.w2l[6] * -wo.z,
-                                     light.w2l[8] * -wo.x + light.w2l[9] * -wo.y + light.w2l[10] * -wo.z));
+            if (C.lightKind == PVOL_LIGHT_SPOT) {
+                V3 wl = normalize(v3(C.w2l[0] * -wo.x + C.w2l[1] * -wo.y + C.w2l[2] * -wo.z,
+                                     C.w2l[3] * -wo.x + C.w2l[4] * -wo.y + C.w2l[5] * -wo.z,
+                                     C.w2l[6] * -wo.x + C.w2l[7] * -wo.y + C.w2l[8] * -wo.z));
                 const float costheta = wl.z;   // SpotLight::Falloff, spot.cpp:60-69; 0 means L.IsBlack()
                 float fall = 1.f;
-                if (costheta < light.cosTotalWidth) fall = 0.f;
-                else if (!(costheta > light.cosFalloffStart)) {
-                    const float delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+                if (costheta < C.cosTotalWidth) fall = 0.f;
+                else if (!(costheta > C.cosFalloffStart)) {
+                    const float delta = (costheta - C.cosTotalWidth) / (C.cosFalloffStart - C.cosTotalWidth);
                     fall = delta * delta * delta * delta;
                 }
                 if (fall == 0.f) continue;
             }
         }
-        if (!lane_occluded(S, vis)) ++u;
+        // Scene::IntersectP over the world triangles, staged in LDS (12 floats each): every lane reads the same words
+        // (broadcast), no early exit, so the loads of all triangles are in flight together
+        bool occ = false;
+        for (int t = 0; t < C.nTris; ++t) {
+            const f4 a = *reinterpret_cast<const f4 *>(ltri + 12 * t), b = *reinterpret_cast<const f4 *>(ltri + 12 * t + 4),
+                     c = *reinterpret_cast<const f4 *>(ltri + 12 * t + 8);
+            occ = occ | tri_hit_v(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), vis);
+        }
+        if (!occ) ++u;
     }
     return 4u + 7u * (uint32_t)nSamples + u;
 }
@@ -204,6 +234,14 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
     L.time = L.image + 2 * T.spp;
     L.scatter = L.time + T.spp;
     L.oth = reinterpret_cast<uint32_t *>(L.scatter + T.spp);
+    const size_t triOff = (((size_t)MT_N * 4 + (FUSED ? (size_t)((S.maxSteps + 1) & ~1) * 4 : 0) + (size_t)T.spp * 5 * 4) + 15) & ~(size_t)15;
+    float *ltri = reinterpret_cast<float *>(lds + triOff);   // 16-byte aligned: read as float4
+    for (int i = lane; i < S.nTris * 12; i += LANES) {
+        const int t = i / 12, c = i - 12 * t;
+        const DevTri &tr = S.tris[t];
+        ltri[i] = c < 3 ? tr.p1[c] : c < 6 ? tr.p2[c - 3] : c < 9 ? tr.p3[c - 6] : 0.f;
+    }
+    __syncthreads();
     const pvol_stream st = A.streams[sidx];
     const uint32_t begin = A.sliceK * A.sliceM;
     if (begin >= st.n_rays && !(A.sliceK == 0)) return;
@@ -230,6 +268,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
     const bool blackS = spec_is_black(ld4(S.sigS, q));
     const bool lightBlack = S.nLights > 0 ? spec_is_black(ld4(S.lights[0].intensity, q)) : true;
     pvol_ray *rays = T.rays;
+    const CountConsts CC = count_consts(S);
     for (uint32_t k = begin; k < end; k += T.spp) {
         const uint32_t pix = k / T.spp;
         const int xPos = w.x + (int)(pix % width), yPos = w.z + (int)(pix / width);
@@ -259,11 +298,11 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
                 T.xy[2 * ri + 1] = imageY;
             }
             if (!FUSED) {
-                uint32_t nd = on ? tile_count_draws(S, o, d, maxt, su, blackS, lightBlack) : 0u;
+                uint32_t nd = (on && !(T.debugSkip & 2u)) ? tile_count_draws(CC, ltri, o, d, maxt, su, blackS, lightBlack) : ((T.debugSkip & 2u) ? 270u : 0u);
                 // wave total (integer adds in any order are exact)
                 unsigned long long tot = nd;
                 for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-                rng_skip<true>(rng, tot, lane);
+                if (!(T.debugSkip & 4u)) rng_skip<true>(rng, tot, lane);
             } else {
                 for (int j = 0; j < cnt; ++j) {
                     pvol_ray pr;
@@ -290,7 +329,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
 }
 
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused) {
-    return (size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4;
+    return (((size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4 + 15) & ~(size_t)15) + PVOL_MAX_TRIS * 12 * 4 + 64;
 }
 
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream) {

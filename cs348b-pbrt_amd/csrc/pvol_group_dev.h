@@ -20,6 +20,7 @@
 #define GRP_PITCH (GRP_CAP + 4)   // floats per bucket component (x | y | z | photon index), padded for the 4-wide passes
 #define GRP_WIDEN 1.7f   // a lane's search radius^2 may grow to this multiple of its guess where the bucket covers it
 #define GRP_MINI 8    // values of the k-th's bin a lane can sort
+#define GRP_TRI_ROWS 8   // scenes with a distant light and at most this many triangles test shadow rays against precomputed rows
 #define GRP_WPE 2
 
 struct GroupLds {
@@ -30,6 +31,7 @@ struct GroupLds {
     unsigned short *order;  // GRP_CH: chunk-local ray index by rank of scatter offset
     float *cst;             // 9 x 32 floats: sigA, sigS, le, albedo, light-0 intensity, 1/sigS, CIE X, Y, Z weights
     unsigned short *clist;  // GRP_CAP bucket slots whose photon belongs to some lane's k-NN set
+    float *trows;           // GRP_TRI_ROWS x 16 floats: per-triangle shadow-ray precomputation for a distant light
 };
 
 // Photons within Rs of c -> LDS bucket.  Returns the count, or -1 if the bucket would overflow.
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     L.order = reinterpret_cast<unsigned short *>(L.ubuf + GRP_CH);   // GRP_CH shorts; both fit in mini + hist
     L.cst = reinterpret_cast<float *>(L.hist + (GRP_BINS / 8) * LANES);
     L.clist = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
+    L.trows = reinterpret_cast<float *>(lds + ((PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 2) * 2 + 15) & ~15));
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
     const int q = lane & 7;
     const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
@@ -191,6 +194,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     __syncthreads();
     const f4 *cA = reinterpret_cast<const f4 *>(L.cst), *cS = cA + 8, *cLe = cA + 16, *cAl = cA + 24, *cI = cA + 32, *cRs = cA + 40;
     const f4 *cX = cA + 48, *cY = cA + 56, *cZ = cA + 64;
+    const bool rowsOK = nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS;
+    if (rowsOK) tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), L.trows, lane);
     const int k = S.nUsed;
     const float wIso = 1.f / (4.f * K_PI);
     Rng rngNone;
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         }
                     }
                     const bool black = (fallReg == 0.f) || lightBlack;
-                    if (!black && !lane_occluded(S, vis)) {
+                    if (!black && !(rowsOK ? tri_rows_occluded(L.trows, S.nTris, vis.o, vis.d, vis.mint, vis.maxt) : lane_occluded(S, vis))) {
                         lit = true;
                         V3 dv = xform_vector(S.w2v, vis.d);
                         V3 dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
@@ -631,7 +636,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;   // the fallback candidate arrays alias the bucket
-    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 2) * 2;
+    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (((GRP_CAP + 2) * 2 + 15) & ~15) + GRP_TRI_ROWS * 64;
 }
 
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {

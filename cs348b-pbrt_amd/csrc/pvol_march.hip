@@ -453,6 +453,31 @@ __device__ __forceinline__ bool tri_test(const TriPre &t, V3 o, V3 d, float mint
     if (tt < mint || tt > maxt) return false;
     return true;
 }
+// The same precomputation parked in LDS, one 16-float row per triangle (p1 | e1 | e2 | s1 | invDivisor, valid), for the
+// kernels that test one shadow ray PER LANE against every triangle: with a distant light all shadow rays share their
+// direction, so the first cross product (double precision as in geometry.h:477-484), the divisor and its reciprocal are
+// computed once per kernel instead of once per lane, step and triangle.
+__device__ void tri_rows_prepare(const DevScene &S, V3 d, float *rows, int lane) {
+    if (lane < S.nTris) {
+        const TriPre t = tri_prepare(S, d, lane);
+        float *r = rows + 16 * lane;
+        r[0] = t.p1.x; r[1] = t.p1.y; r[2] = t.p1.z; r[3] = t.e1.x; r[4] = t.e1.y; r[5] = t.e1.z; r[6] = t.e2.x; r[7] = t.e2.y;
+        r[8] = t.e2.z; r[9] = t.s1.x; r[10] = t.s1.y; r[11] = t.s1.z; r[12] = t.invDivisor; r[13] = t.valid ? 1.f : 0.f; r[14] = 0.f; r[15] = 0.f;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ bool tri_rows_occluded(const float *rows, int nTris, V3 o, V3 d, float mint, float maxt) {
+    bool occ = false;
+    for (int t = 0; t < nTris; ++t) {
+        const f4 r0 = *reinterpret_cast<const f4 *>(rows + 16 * t), r1 = *reinterpret_cast<const f4 *>(rows + 16 * t + 4),
+                 r2 = *reinterpret_cast<const f4 *>(rows + 16 * t + 8), r3 = *reinterpret_cast<const f4 *>(rows + 16 * t + 12);
+        TriPre tp;
+        tp.p1 = v3(r0.x, r0.y, r0.z); tp.e1 = v3(r0.w, r1.x, r1.y); tp.e2 = v3(r1.z, r1.w, r2.x); tp.s1 = v3(r2.y, r2.z, r2.w);
+        tp.invDivisor = r3.x; tp.valid = r3.y != 0.f;
+        occ = occ | tri_test(tp, o, d, mint, maxt);
+    }
+    return occ;
+}
 // tau() of a homogeneous extent along a ray that STARTS INSIDE it (mint == 0): BBox::IntersectP
 // (core/geometry.cpp:68-86) then leaves t0 == 0 exactly, so only the far slab distances remain.
 // pv = WorldToVolume(o), dvInv = 1 / WorldToVolume(d) per axis.  Returns Distance(ray(0), ray(t1)).

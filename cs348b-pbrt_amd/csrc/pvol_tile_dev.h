@@ -133,11 +133,30 @@ __device__ __forceinline__ void tile_camera_ray(const TileArgs &T, float imageX,
 }
 
 // Scene::Intersect as SamplerRenderer::Li uses it (samplerrenderer.cpp:236-249): only the clipped maxt matters here
-__device__ __forceinline__ float tile_clip(const DevScene &S, V3 o, V3 d) {
+__device__ __forceinline__ bool tri_closest_v(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, float *tHit) {
+    V3 e1 = p2 - p1, e2 = p3 - p1;
+    V3 s1 = cross(d, e2);
+    float divisor = dot(s1, e1);
+    if (divisor == 0.f) return false;
+    float invDivisor = 1.f / divisor;
+    V3 s = o - p1;
+    float b1 = dot(s, s1) * invDivisor;
+    if (b1 < 0.f || b1 > 1.f) return false;
+    V3 s2 = cross(s, e1);
+    float b2 = dot(d, s2) * invDivisor;
+    if (b2 < 0.f || b1 + b2 > 1.f) return false;
+    float t = dot(e2, s2) * invDivisor;
+    if (t < mint || t > maxt) return false;
+    *tHit = t;
+    return true;
+}
+__device__ __forceinline__ float tile_clip(const float *ltri, int nTris, V3 o, V3 d) {
     float mt = INFINITY;
-    for (int i = 0; i < S.nTris; ++i) {
+    for (int i = 0; i < nTris; ++i) {
+        const f4 a = *reinterpret_cast<const f4 *>(ltri + 12 * i), b = *reinterpret_cast<const f4 *>(ltri + 12 * i + 4),
+                 c = *reinterpret_cast<const f4 *>(ltri + 12 * i + 8);
         float t;
-        if (tri_closest(S.tris[i], o, d, 0.f, mt, &t)) mt = t;
+        if (tri_closest_v(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), o, d, 0.f, mt, &t)) mt = t;
     }
     return mt;
 }
@@ -167,7 +186,7 @@ __device__ __forceinline__ CountConsts count_consts(const DevScene &S) {
 
 // Number of RandomUInt calls of one Li() when no roulette can fire and at most one light exists: 4 + 6n + n + u
 // (photonvolume.cpp:112-222; same per-step tests as march_ray_blocked's scalar phase).  One ray per lane.
-__device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack) {
+__device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, const float *trows, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack, uint32_t dbg = 0u) {
     float t0, t1;
     // vol_intersect: BBox::IntersectP of the ray taken to volume space (core/geometry.cpp:68-86)
     if (C.volKind == PVOL_VOLUME_NONE || !box_intersect(C.lo, C.hi, xform_point(C.w2v, o), xform_vector(C.w2v, d), 0.f, maxt, &t0, &t1) || (t1 - t0) == 0.f) return 0u;
@@ -176,7 +195,7 @@ __device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, V3
     float tcur = t0 + scatterU * step;
     uint32_t u = 0;
     const bool tryLight = !blackS && C.nLights > 0 && !lightBlack;
-    if (!tryLight) return 4u + 7u * (uint32_t)nSamples;
+    if (!tryLight || (dbg & 16u)) return 4u + 7u * (uint32_t)nSamples;
     for (int j = 0; j < nSamples; ++j) {
         const V3 p = o + d * tcur;
         tcur += step;
@@ -207,10 +226,14 @@ __device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, V3
         // Scene::IntersectP over the world triangles, staged in LDS (12 floats each): every lane reads the same words
         // (broadcast), no early exit, so the loads of all triangles are in flight together
         bool occ = false;
-        for (int t = 0; t < C.nTris; ++t) {
-            const f4 a = *reinterpret_cast<const f4 *>(ltri + 12 * t), b = *reinterpret_cast<const f4 *>(ltri + 12 * t + 4),
-                     c = *reinterpret_cast<const f4 *>(ltri + 12 * t + 8);
-            occ = occ | tri_hit_v(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), vis);
+        if (trows) {   // distant light: direction-only terms precomputed per triangle
+            if (!(dbg & 8u)) occ = tri_rows_occluded(trows, C.nTris, vis.o, vis.d, vis.mint, vis.maxt);
+        } else {
+            for (int t = 0; t < ((dbg & 8u) ? 0 : C.nTris); ++t) {
+                const f4 a = *reinterpret_cast<const f4 *>(ltri + 12 * t), b = *reinterpret_cast<const f4 *>(ltri + 12 * t + 4),
+                         c = *reinterpret_cast<const f4 *>(ltri + 12 * t + 8);
+                occ = occ | tri_hit_v(v3(a.x, a.y, a.z), v3(a.w, b.x, b.y), v3(b.z, b.w, c.x), vis);
+            }
         }
         if (!occ) ++u;
     }
@@ -242,6 +265,11 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
         ltri[i] = c < 3 ? tr.p1[c] : c < 6 ? tr.p2[c - 3] : c < 9 ? tr.p3[c - 6] : 0.f;
     }
     __syncthreads();
+    float *trows = 0;
+    if (!FUSED && S.nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT) {
+        trows = ltri + PVOL_MAX_TRIS * 12;
+        tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), trows, lane);
+    }
     const pvol_stream st = A.streams[sidx];
     const uint32_t begin = A.sliceK * A.sliceM;
     if (begin >= st.n_rays && !(A.sliceK == 0)) return;
@@ -288,7 +316,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
                 tm = lerpf(L.time[i], T.shutterOpen, T.shutterClose);
                 su = L.scatter[i];
                 tile_camera_ray(T, imageX, imageY, &o, &d);
-                maxt = tile_clip(S, o, d);
+                maxt = tile_clip(ltri, S.nTris, o, d);
                 pvol_ray pr;
                 pr.o[0] = o.x; pr.o[1] = o.y; pr.o[2] = o.z; pr.mint = 0.f;
                 pr.d[0] = d.x; pr.d[1] = d.y; pr.d[2] = d.z; pr.maxt = maxt;
@@ -298,7 +326,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
                 T.xy[2 * ri + 1] = imageY;
             }
             if (!FUSED) {
-                uint32_t nd = (on && !(T.debugSkip & 2u)) ? tile_count_draws(CC, ltri, o, d, maxt, su, blackS, lightBlack) : ((T.debugSkip & 2u) ? 270u : 0u);
+                uint32_t nd = (on && !(T.debugSkip & 2u)) ? tile_count_draws(CC, ltri, trows, o, d, maxt, su, blackS, lightBlack, T.debugSkip) : ((T.debugSkip & 2u) ? 270u : 0u);
                 // wave total (integer adds in any order are exact)
                 unsigned long long tot = nd;
                 for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
@@ -329,7 +357,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
 }
 
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused) {
-    return (((size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4 + 15) & ~(size_t)15) + PVOL_MAX_TRIS * 12 * 4 + 64;
+    return (((size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4 + 15) & ~(size_t)15) + PVOL_MAX_TRIS * 12 * 4 + PVOL_MAX_TRIS * 16 * 4 + 64;
 }
 
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream) {

@@ -324,31 +324,39 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 bool viaPlan = false;   // acc holds a raw flux sum of exactly k photons (scaled below)
                 const uint64_t needMask = __ballot(need);
                 if (needMask) {
+                    // The bucket plan, at most twice: lanes whose guessed radius turned out too small or too large get one more
+                    // shared attempt with a corrected radius (they come in clusters: ~11 lanes per affected step on C2) before
+                    // the per-lane exact lookup takes whatever is left.
+                    float Tretry = 0.f;
+                    for (int attempt = 0; attempt < 2; ++attempt) {
+                    const bool needP = need && !done && (attempt == 0 || Tretry > 0.f);
+                    if (!__ballot(needP)) break;
                     // per-lane search radius^2: 1.3 x the larger of this ray's previous step and the previous group's
                     // mean at this step; the full radius when neither exists.  The bucket covers the largest of them.
                     float gbl = lastRk;
                     if (j < PREV_N) gbl = fmaxf(gbl, M.prevRk[j]);
                     float Tl = (gbl > 0.f && gbl * A.grpGuess < S.maxDistSq) ? gbl * A.grpGuess : S.maxDistSq;
+                    if (attempt == 1) { Tl = Tretry; gbl = 0.f; }   // second chance: the radius the first attempt asked for, no widening
                     bool fullR = !(Tl < S.maxDistSq);
-                    float T = need ? Tl : 0.f;
+                    float T = needP ? Tl : 0.f;
                     T = wave_max(T);
                     int Mb = -1;
                     if (k >= 10 && k <= 64) {
                         // centre and spread of the query points
                         const float big = 3.0e38f;
-                        float lx = need ? p.x : big, ly = need ? p.y : big, lz = need ? p.z : big;
-                        float hx = need ? p.x : -big, hy = need ? p.y : -big, hz = need ? p.z : -big;
+                        float lx = needP ? p.x : big, ly = needP ? p.y : big, lz = needP ? p.z : big;
+                        float hx = needP ? p.x : -big, hy = needP ? p.y : -big, hz = needP ? p.z : -big;
                         lx = -wave_max(-lx); ly = -wave_max(-ly); lz = -wave_max(-lz);
                         hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
                         const V3 c = v3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
-                        float rho = need ? len(p - c) : 0.f;
+                        float rho = needP ? len(p - c) : 0.f;
                         rho = wave_max(rho);
                         const float Rs = (sqrtf(T) + rho) * 1.0001f + 1e-6f;   // superset by the triangle inequality, with rounding slack
                         unsigned long long tst = 0, ts0 = STATS ? stamp() : 0ull;
                         Mb = stage_bucket(S, M.G, L.pos, c, Rs, lane, tst);
                         // the bucket covers more than this lane asked for when other lanes guessed larger: take it (up to
                         // GRP_WIDEN x the guess) -- a wider search ball costs this lane nothing and spares it a failed guess
-                        if (need && gbl > 0.f) {
+                        if (needP && gbl > 0.f) {
                             const float cover = (sqrtf(T) + rho) - len(p - c);
                             Tl = fminf(S.maxDistSq, fmaxf(Tl, fminf(cover * cover, gbl * GRP_WIDEN)));
                             fullR = !(Tl < S.maxDistSq);
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         for (int wd = 0; wd < GRP_BINS / 8; ++wd) L.hist[wd * LANES + lane] = 0u;
                         int below = 0, cnt = 0;
                         float dmax = 0.f;
-                        const float TlEff = need ? Tl : -1.f;   // lanes without a lookup accept nothing
+                        const float TlEff = needP ? Tl : -1.f;   // lanes without a lookup accept nothing
                         const uint32_t histBase = (uint32_t)lane;
                         for (int c0 = 0; c0 < Mb; c0 += 4) {
                             const nf4 dd = GRP_D2X4(c0);
@@ -391,10 +399,14 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 atomicAdd(&L.hist[(uint32_t)(hb >> 3) * LANES + histBase], inc);
                             }
                         }
-                        bool ok = need && cnt >= k && below < k;
+                        bool ok = needP && cnt >= k && below < k;
                         // the full radius holds fewer than k photons: all of them count, r^2 = the farthest (photonvolume.cpp:76-105)
-                        const bool shortSet = need && fullR && cnt < k && cnt < 250;
-                        if (STATS) wc.diag0 += __popcll(__ballot(need && ((cnt < k && !shortSet) || (cnt >= k && below >= k))));   // radius guess too small / too large
+                        const bool shortSet = needP && fullR && cnt < k && cnt < 250;
+                        if (STATS && attempt == 0) wc.diag0 += __popcll(__ballot(needP && ((cnt < k && !shortSet) || (cnt >= k && below >= k))));   // radius guess too small / too large
+                        if (attempt == 0 && needP) {   // what a second attempt should search: 2.2 x (too few found) or 0.3 x (k-th below the histogram)
+                            if (cnt < k && !shortSet) Tretry = fminf(S.maxDistSq, 2.2f * Tl);
+                            else if (cnt >= k && below >= k) Tretry = 0.3f * Tl;
+                        }
                         int bstar = -1, cumBelow = 0, binCount = 0;
                         int cumAll = below;
                         {
@@ -431,7 +443,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                     L.mini[nb * LANES + lane] = d2;   // kept only if inBin: the slot is overwritten otherwise
                                     nb += inBin;
                                     const int possible = inT & (bin <= bLe ? 1 : 0);
-                                    L.clist[nC] = (unsigned short)(c0 + u);   // every lane stores the same value; kept only if some lane may need it
+                                    L.clist[nC] = (unsigned short)(c0 + u);   // every lane stores the same value; kept only if some lane may needP it
                                     nC += __ballot(possible != 0) != 0ull ? 1 : 0;
                                 }
                             }
@@ -449,15 +461,15 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             }
                         }
                         const int m = k - cumBelow;   // 1-based rank of the k-th inside its bin
-                        rk = sv[0];
+                        float rkC = sv[0];   // this attempt's k-th distance^2 (rk itself belongs to the lanes already served)
                         int nLessIn = 0;
 #pragma unroll
-                        for (int t = 1; t < GRP_MINI; ++t) rk = (m == t + 1) ? sv[t] : rk;
+                        for (int t = 1; t < GRP_MINI; ++t) rkC = (m == t + 1) ? sv[t] : rkC;
 #pragma unroll
-                        for (int t = 0; t < GRP_MINI; ++t) nLessIn += (sv[t] < rk) ? 1 : 0;
-                        int quota0 = k - cumBelow - nLessIn;   // ties at rk are taken in bucket order
-                        ok = ok && rk < Tl;
-                        if (shortSet) { ok = true; rk = dmax; quota0 = 256; }
+                        for (int t = 0; t < GRP_MINI; ++t) nLessIn += (sv[t] < rkC) ? 1 : 0;
+                        int quota0 = k - cumBelow - nLessIn;   // ties at rkC are taken in bucket order
+                        ok = ok && rkC < Tl;
+                        if (shortSet) { ok = true; rkC = dmax; quota0 = 256; }
                         const unsigned long long tp3 = STATS ? stamp() : 0ull;
                         if (STATS) wc.cySelect += tp3 - tp1;
                         // ---- pass 3: flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
@@ -479,10 +491,10 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 #pragma unroll
                                 for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
                                 const float dA = dist2_ref(make_float4(ax, ay, az, 0.f), p), dB = dist2_ref(make_float4(bx, by, bz, 0.f), p);
-                                bool mA = ok && dA < rk;
-                                if (ok && dA == rk && quota > 0) { mA = true; --quota; }
-                                bool mB = ok && dB < rk;
-                                if (ok && dB == rk && quota > 0) { mB = true; --quota; }
+                                bool mA = ok && dA < rkC;
+                                if (ok && dA == rkC && quota > 0) { mA = true; --quota; }
+                                bool mB = ok && dB < rkC;
+                                if (ok && dB == rkC && quota > 0) { mB = true; --quota; }
                                 const float fA = mA ? 1.f : 0.f, fB = mB ? 1.f : 0.f;
 #pragma unroll
                                 for (int qq = 0; qq < 8; ++qq) {
@@ -497,9 +509,10 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             }
                         }
 #undef GRP_D2X4
-                        if (ok) { done = true; viaPlan = true; if (shortSet) nFoundLane = cnt; }
+                        if (ok) { done = true; viaPlan = true; rk = rkC; if (shortSet) nFoundLane = cnt; }
                         if (STATS) { wc.kept += (unsigned long long)k * __popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
                     }
+                    }   // attempt
                     // ---- lanes the plan did not serve: the wave-cooperative exact lookup, one lane at a time
                     uint64_t todo = __ballot(need && !done);
                     WaveCounters wsave = wc;
@@ -526,7 +539,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         }
                         if (lane == l) rk = rkl;
                     }
-                    if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
+                    if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; if (nfb) wc.lt10 += 1; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
                     const float rkGuess = (need && nFoundLane >= k) ? rk : 0.f;   // as lphoton's rkOut: a k-th distance exists only for full sets
                     {   // mean k-th distance^2 of the group at this step -> guess of the next group
                         float sr = rkGuess, sn = rkGuess > 0.f ? 1.f : 0.f;

@@ -259,7 +259,7 @@ def main():
     if args.photon_source == "shoot":
         # PhotonShooter::Preprocess on the device; every rank shoots the same map (same seeds): replicated, no traffic
         pv.preprocess(args.shoot_tasks)
-        photons = pv.download_photons() if (rank == 0 and not args.no_cpu_baseline) else None
+        photons = pv.download_photons() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
         photon_note = "device shooter, %d virtual tasks" % args.shoot_tasks
     else:
         photons = synth_photons(args.photons)
@@ -363,16 +363,17 @@ def main():
         }
         # roofline of the dominant kernel (li_group_kernel here): algorithmic bytes = B_lookup x lookups, SURVEY 8(d)
         cpu, ctr = (None, None)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a rank-0, N=1 leg
             if args.driver == "tile":
                 cpu, ctr = cpu_baseline_render(scene, params, photons, cam, film, smp)
             else:
                 cpu, ctr = cpu_baseline(scene, params, photons, args.xres, args.yres)
             res["cpu_baseline"] = cpu
         stats = pv.stats() if args.stats else None
-        V = (ctr["n_nodes_visited"] / max(1, ctr["n_lookups"])) if ctr else 323.0
-        K = (ctr["n_kept"] / max(1, ctr["n_lookups"])) if ctr else 50.0
-        steps_per_ray = (ctr["n_steps"] / max(1, ctr["n_rays"])) if ctr else 33.8
+        # without the CPU leg (N > 1, --no-cpu-baseline): the figures the N=1 run of this workload measured (profiles/)
+        V = (ctr["n_nodes_visited"] / max(1, ctr["n_lookups"])) if ctr else 328.6
+        K = (ctr["n_kept"] / max(1, ctr["n_lookups"])) if ctr else 46.6
+        steps_per_ray = (ctr["n_steps"] / max(1, ctr["n_rays"])) if ctr else 37.1
         b_lookup = 20.0 * V + 132.0 * K
         bytes_per_launch = b_lookup * steps_per_ray * n_rays + 16.0 * n_rays + 48.0 * n_rays
         achieved = bytes_per_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0

@@ -41,6 +41,11 @@
 #include "volumes/rainbow.h"
 #include "volumes/volumegrid.h"
 #include "textures/constant.h"
+#include "film.h"
+#include "filter.h"
+#include "cameras/perspective.h"
+#include "film/image.h"
+#include "samplers/lowdiscrepancy.h"
 #undef private
 #undef protected
 
@@ -208,6 +213,40 @@ private:
             Severe("photonvolume_hip: material not supported on the photon path (matte, glass)");
         }
         return o;
+    }
+
+    // Tile driver (include/pvol.h): what a renderer calls INSTEAD of enqueueing SamplerRendererTasks
+    // (renderers/samplerrenderer.cpp:206-221) when the camera is a pinhole PerspectiveCamera, the film an ImageFilm, the
+    // sampler an LDSampler and the surface integrator contributes nothing.  d_pixels / d_rgb are device buffers
+    // (x*y*4 and x*y*3 floats, d_pixels zeroed); the resolved RGB then goes through ::WriteImage as before.
+    int RenderTasks(const PerspectiveCamera *camera, const ImageFilm *film, const LDSampler *sampler, const Sample *origSample,
+                    int nTasks, float *d_pixels, float *d_rgb, void *hipStream) const {
+        pvol_camera cam;
+        memset(&cam, 0, sizeof(cam));
+        putMat(cam.raster_to_camera, camera->RasterToCamera.m);
+        putMat(cam.camera_to_world, camera->CameraToWorld.startTransform->m);   // static cameras only
+        cam.shutter_open = camera->shutterOpen; cam.shutter_close = camera->shutterClose;
+        cam.lens_radius = camera->lensRadius; cam.focal_distance = camera->focalDistance;
+        pvol_film f;
+        memset(&f, 0, sizeof(f));
+        f.x_resolution = film->xResolution; f.y_resolution = film->yResolution;
+        f.filter_xwidth = film->filter->xWidth; f.filter_ywidth = film->filter->yWidth;
+        memcpy(f.filter_table, film->filterTable, sizeof(f.filter_table));
+        pvol_sampler smp;
+        memset(&smp, 0, sizeof(smp));
+        film->GetSampleExtent(&smp.x_start, &smp.x_end, &smp.y_start, &smp.y_end);
+        smp.pixel_samples = sampler->samplesPerPixel;
+        smp.n_tasks = nTasks;
+        smp.n1d_count = origSample->n1D.size(); smp.n2d_count = origSample->n2D.size();
+        if (smp.n1d_count > PVOL_MAX_SAMPLE_ARRAYS || smp.n2d_count > PVOL_MAX_SAMPLE_ARRAYS) return PVOL_E_LIMIT;
+        for (uint32_t i = 0; i < smp.n1d_count; ++i) smp.n1d[i] = origSample->n1D[i];
+        for (uint32_t i = 0; i < smp.n2d_count; ++i) smp.n2d[i] = origSample->n2D[i];
+        smp.tau_index = tauSampleOffset; smp.scatter_index = scatterSampleOffset;
+        std::vector<uint32_t> tasks(nTasks);
+        for (int t = 0; t < nTasks; ++t) tasks[t] = t;
+        int rc = pvol_render_tasks_device(ctx, &cam, &f, &smp, tasks.data(), nTasks, d_pixels, NULL, hipStream);
+        if (rc == PVOL_OK) rc = pvol_film_resolve_device(ctx, &f, d_pixels, d_rgb, hipStream);
+        return rc;
     }
 
     pvol_params params;

@@ -383,8 +383,13 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         float dmax = 0.f;
                         const float TlEff = needP ? Tl : -1.f;   // lanes without a lookup accept nothing
                         const uint32_t histBase = (uint32_t)lane;
+                        nf4 nX = *reinterpret_cast<const nf4 *>(bX), nY = *reinterpret_cast<const nf4 *>(bY), nZ = *reinterpret_cast<const nf4 *>(bZ);
                         for (int c0 = 0; c0 < Mb; c0 += 4) {
-                            const nf4 dd = GRP_D2X4(c0);
+                            // the next quartet's coordinates are requested before this one's arithmetic (the padded bucket makes the
+                            // read past the end harmless)
+                            const nf4 dx_ = nX - px4, dy_ = nY - py4, dz_ = nZ - pz4;
+                            nX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); nY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); nZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
+                            const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {   // branch-free: predicates are 0/1 integers, the histogram add is +0 when not counted
                                 const float d2 = dd[u];
@@ -431,8 +436,11 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             const float TlPlan = planLane ? Tl : -1.f;
                             const int bEq = ok ? bstar : -1000;                    // bin whose values are kept (none for short sets)
                             const int bLe = shortSet ? 1000 : (ok ? bstar : -1000);   // last bin that can hold a member
+                            nf4 mX = *reinterpret_cast<const nf4 *>(bX), mY = *reinterpret_cast<const nf4 *>(bY), mZ = *reinterpret_cast<const nf4 *>(bZ);
                             for (int c0 = 0; c0 < Mb; c0 += 4) {
-                                const nf4 dd = GRP_D2X4(c0);
+                                const nf4 dx_ = mX - px4, dy_ = mY - py4, dz_ = mZ - pz4;
+                                mX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); mY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); mZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
+                                const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
 #pragma unroll
                                 for (int u = 0; u < 4; ++u) {   // branch-free; bins below the histogram range count as -1
                                     const float d2 = dd[u];

@@ -167,8 +167,9 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     L.order = reinterpret_cast<unsigned short *>(L.ubuf + GRP_CH);   // GRP_CH shorts; both fit in mini + hist
     L.cst = reinterpret_cast<float *>(L.hist + (GRP_BINS / 8) * LANES);
     L.clist = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
-    L.trows = reinterpret_cast<float *>(lds + ((PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 2) * 2 + 15) & ~15));
+    L.trows = reinterpret_cast<float *>(lds + ((PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 4) * 2 + 15) & ~15));
     for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
+    for (int i = lane; i < GRP_CAP + 4; i += LANES) L.clist[i] = 0;   // entries are read up to three past the list: keep them valid slots
     const int q = lane & 7;
     const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
     const f4 sigT4 = sigA4 + sigS4;
@@ -490,11 +491,17 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         if (nC && __ballot(ok)) {
                             typedef const __attribute__((address_space(4))) nf4 cf4;
                             int quota = quota0;
+                            // the LDS side of the next pair (list entries, coordinates, photon indices) is read one iteration ahead
+                            int nca = (int)L.clist[0], ncb = (int)L.clist[1];
+                            float nax = bX[nca], nay = bY[nca], naz = bZ[nca], nbx = bX[ncb], nby = bY[ncb], nbz = bZ[ncb];
+                            float nia = bI[nca], nib = bI[ncb];
                             for (int i = 0; i < nC; i += 2) {
-                                const int ca = (int)L.clist[i], cb2 = (int)L.clist[i + 1];
-                                const float ax = bX[ca], ay = bY[ca], az = bZ[ca], bx = bX[cb2], by = bY[cb2], bz = bZ[cb2];
-                                cf4 *ra = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[ca])) * 8);
-                                cf4 *rb = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[cb2])) * 8);
+                                const float ax = nax, ay = nay, az = naz, bx = nbx, by = nby, bz = nbz;
+                                cf4 *ra = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nia)) * 8);
+                                cf4 *rb = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nib)) * 8);
+                                nca = (int)L.clist[i + 2]; ncb = (int)L.clist[i + 3];   // past the end: stale but in-range slots, never used
+                                nax = bX[nca]; nay = bY[nca]; naz = bZ[nca]; nbx = bX[ncb]; nby = bY[ncb]; nbz = bZ[ncb];
+                                nia = bI[nca]; nib = bI[ncb];
                                 nf4 rowA[8], rowB[8];
 #pragma unroll
                                 for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;   // the fallback candidate arrays alias the bucket
-    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (((GRP_CAP + 2) * 2 + 15) & ~15) + GRP_TRI_ROWS * 64;
+    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (((GRP_CAP + 4) * 2 + 15) & ~15) + GRP_TRI_ROWS * 64;
 }
 
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {

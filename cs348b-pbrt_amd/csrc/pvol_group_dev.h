@@ -554,7 +554,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         }
                         if (lane == l) rk = rkl;
                     }
-                    if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; if (nfb) wc.lt10 += 1; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
+                    if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
                     const float rkGuess = (need && nFoundLane >= k) ? rk : 0.f;   // as lphoton's rkOut: a k-th distance exists only for full sets
                     {   // mean k-th distance^2 of the group at this step -> guess of the next group
                         float sr = rkGuess, sn = rkGuess > 0.f ? 1.f : 0.f;

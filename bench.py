@@ -184,7 +184,7 @@ def cpu_baseline_render(scene, params, photons, cam, film, smp, budget_s=20.0):
     import orc
     pkg = importlib.import_module("cs348b-pbrt_amd")
     abi = pkg.abi
-    cores = max(1, min(os.cpu_count() or 1, 32))
+    cores = max(1, min(os.cpu_count() or 1, 16))   # the GPU box grants a 16-core CPU share per GPU
     o = orc.Oracle(abi.SceneHolder(scene), params)
     t0 = time.time()
     o.set_photons(*photons)
@@ -192,9 +192,10 @@ def cpu_baseline_render(scene, params, photons, cam, film, smp, budget_s=20.0):
     o.counters(reset=True)
     rng = np.random.default_rng(7)
     n_tasks = smp.n_tasks
-    # bounded sample: start from ~0.25 M samples (a few seconds at ~0.04 Msamples/s) and double while a batch stays short
+    # bounded sample: the oracle runs one render task per thread (a task is sequential: one RNG stream), so a batch needs at
+    # least `cores` tasks to use the cores it reports; small tasks are batched further up to ~0.25 M samples
     per_task = (film.x_resolution + 5) * (film.y_resolution + 5) * smp.pixel_samples / n_tasks
-    batch = int(max(1, min(n_tasks, round(250000.0 / per_task))))
+    batch = int(max(1, min(n_tasks, max(cores, round(250000.0 / per_task)))))
     done, elapsed = 0, 0.0
     while elapsed < budget_s:
         pick = rng.choice(n_tasks, min(batch, n_tasks), replace=False).astype(np.uint32)

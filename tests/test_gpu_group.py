@@ -59,7 +59,7 @@ def _ctx(pvol, s, p, photons):
 
 
 @pytest.mark.parametrize("scene_name,n_photons,over", [("volumescene_h", 150000, {}),
-                                                       ("shootbench", 20000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2})])
+                                                       ("shootbench", 8000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2})])
 def test_group_kernel_matches_oracle_on_a_dense_map(pvol, orc, vh_map, scene_name, n_photons, over):
     """volumescene: distant light; shootbench: a SPOT light through a glass prism's triangles (falloff, 1/d^2, occlusion)."""
     if scene_name == "volumescene_h":

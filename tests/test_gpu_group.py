@@ -59,15 +59,27 @@ def _ctx(pvol, s, p, photons):
 
 
 @pytest.mark.parametrize("scene_name,n_photons,over", [("volumescene_h", 150000, {}),
-                                                       ("shootbench", 8000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2})])
+                                                       ("shootbench", 300000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2})])
 def test_group_kernel_matches_oracle_on_a_dense_map(pvol, orc, vh_map, scene_name, n_photons, over):
     """volumescene: distant light; shootbench: a SPOT light through a glass prism's triangles (falloff, 1/d^2, occlusion)."""
     if scene_name == "volumescene_h":
         s, p, photons = vh_map
         pv = _ctx(pvol, s, p, photons)
     else:
+        # the device shooter needs ~100 s for this prism scene whatever the photon count (whole 4096-path blocks per task):
+        # a seeded uniform map inside the medium serves the gather parity just as well
         s = load_scene(scene_name)
-        pv, p, photons = _dense_map(pvol, s, n_photons, 128, **over)   # every virtual task shoots whole 4096-path blocks: few tasks
+        p = abi.params_from_blob(s, **over)
+        rng = np.random.default_rng(11)
+        ext = s["vol.extent"].astype(np.float64)
+        v2w = s["vol.v2w"].reshape(4, 4).astype(np.float64)
+        pvl = ext[:3] + (ext[3:] - ext[:3]) * rng.random((n_photons, 3))
+        P = (pvl @ v2w[:3, :3].T + v2w[:3, 3]).astype(np.float32)
+        W = rng.normal(size=(n_photons, 3)).astype(np.float32)
+        W /= np.linalg.norm(W, axis=1, keepdims=True)
+        A = (rng.random((n_photons, 30)) * 1e-3).astype(np.float32)
+        photons = (P, W, A)
+        pv = _ctx(pvol, s, p, photons)
     try:
         assert pv.photon_count() >= n_photons
         rays, streams = _camera_batch(orc, s, 640, 360, 64, 4096, [700, 2100])   # ~55 pixels x 64 spp per task

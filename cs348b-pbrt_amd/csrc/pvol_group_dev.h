@@ -328,23 +328,13 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     // The bucket plan, at most twice: lanes whose guessed radius turned out too small or too large get one more
                     // shared attempt with a corrected radius (they come in clusters: ~11 lanes per affected step on C2) before
                     // the per-lane exact lookup takes whatever is left.
-                    // Cold start (a wave's first group at this step: no lane has any radius guess): phase 0 resolves ONE lane
-                    // exactly and its k-th distance seeds the bucket plan of all the others (phase 1).
-                    float seed = 0.f;
-                    bool cold;
-                    {
-                        float g0 = need ? lastRk : 0.f;
-                        if (j < PREV_N) g0 = fmaxf(g0, M.prevRk[j]);
-                        cold = wave_max(need ? g0 : 0.f) == 0.f;
-                    }
-                    for (int phase = cold ? 0 : 1; phase < 2; ++phase) {
                     float Tretry = 0.f;
-                    for (int attempt = 0; attempt < (phase == 1 ? 2 : 0); ++attempt) {
+                    for (int attempt = 0; attempt < 2; ++attempt) {
                     const bool needP = need && !done && (attempt == 0 || Tretry > 0.f);
                     if (!__ballot(needP)) break;
                     // per-lane search radius^2: 1.3 x the larger of this ray's previous step and the previous group's
                     // mean at this step; the full radius when neither exists.  The bucket covers the largest of them.
-                    float gbl = fmaxf(lastRk, seed);
+                    float gbl = lastRk;
                     if (j < PREV_N) gbl = fmaxf(gbl, M.prevRk[j]);
                     float Tl = (gbl > 0.f && gbl * A.grpGuess < S.maxDistSq) ? gbl * A.grpGuess : S.maxDistSq;
                     if (attempt == 1) { Tl = Tretry; gbl = 0.f; }   // second chance: the radius the first attempt asked for, no widening
@@ -540,7 +530,6 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     }   // attempt
                     // ---- lanes the plan did not serve: the wave-cooperative exact lookup, one lane at a time
                     uint64_t todo = __ballot(need && !done);
-                    if (phase == 0) todo &= ~todo + 1ull;   // the probe: lowest lane only
                     WaveCounters wsave = wc;
                     const unsigned long long tfb = STATS ? stamp() : 0ull;
                     const int nfb = __popcll(todo);
@@ -563,11 +552,9 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 if (lane == l) acc[4 * qq + cc] = v;
                             }
                         }
-                        if (lane == l) { rk = rkl; done = true; }
-                        if (phase == 0) seed = rkl;
+                        if (lane == l) rk = rkl;
                     }
                     if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
-                    }   // phase
                     const float rkGuess = (need && nFoundLane >= k) ? rk : 0.f;   // as lphoton's rkOut: a k-th distance exists only for full sets
                     {   // mean k-th distance^2 of the group at this step -> guess of the next group
                         float sr = rkGuess, sn = rkGuess > 0.f ? 1.f : 0.f;

@@ -473,7 +473,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         const bool group = !c->noGroup && c->hs.volKind == PVOL_VOLUME_HOMOGENEOUS && c->hs.g == 0.f && c->hs.nPhotons > 0 &&
                            c->hs.nUsed >= 10 && c->hs.nUsed <= 64 && c->hs.candCap <= 4 * 64;
         if (group) {
-            unsigned long long gchunks = ((unsigned long long)nRays + 255ull) / 256ull;
+            unsigned long long gchunks = ((unsigned long long)nRays + 511ull) / 512ull;   // GRP_CH rays per chunk
             uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
             e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, stream);
             c->lastKernel = "li_group_kernel";

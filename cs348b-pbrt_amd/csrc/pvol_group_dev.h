@@ -14,7 +14,7 @@
 // k-NN sets are the reference's; only the order of the flux additions differs (as in lphoton).  A lane whose
 // lookup does not fit the plan (guess too small or too large, crowded bin, bucket overflow) is redone by the
 // wave-cooperative lphoton(), which is always exact.  Spectra live as 30 registers per lane.
-#define GRP_CH 256    // rays per chunk (ordered by scatter_u, then cut into groups of 64)
+#define GRP_CH 512    // rays per chunk (ordered by scatter_u, then cut into groups of 64)
 #define GRP_CAP 512   // bucket capacity (photons)
 #define GRP_BINS 64   // histogram bins over [T/4, T), 4-bit counters (eight per LDS word)
 #define GRP_PITCH (GRP_CAP + 4)   // floats per bucket component (x | y | z | photon index), padded for the 4-wide passes

@@ -10,7 +10,7 @@ TAG=${1:-r01g}
 export TMPDIR=/tmp
 OUT=gpurun_out
 mkdir -p $OUT
-python3 tools/make_prof_inputs.py /tmp/prof_in --spp 64 --xres 640 --yres 360 > $OUT/${TAG}_prof_inputs.log 2>&1 || exit 1
+python3 tools/make_prof_inputs.py /tmp/prof_in --spp 256 --xres 640 --yres 360 > $OUT/${TAG}_prof_inputs.log 2>&1 || exit 1
 ./tools/pvol_prof /tmp/prof_in 2 > $OUT/${TAG}_prof_plain.json 2> $OUT/${TAG}_prof_plain.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- python3 bench.py --no-cpu-baseline > $OUT/${TAG}_bench_traced.json 2> $OUT/${TAG}_bench_traced.err
 echo "trace_exit=$?"

@@ -38,7 +38,7 @@ if agg and plain:
     fetch_kb, write_kb = agg.get("FETCH_SIZE", 0.0), agg.get("WRITE_SIZE", 0.0)
     hbm = (2.0 * fetch_kb + write_kb) * 1024.0   # FETCH_SIZE counts half the bytes on gfx950 (MI355X_MICROARCH.md, HBM)
     summary = {
-        "kernel": "+".join(sorted(kernels)), "driver": "tools/pvol_prof (tools/run_profiles.sh: bench.py scene and photon-map recipe, 640x360 at 64 spp)", "rays": rays,
+        "kernel": "+".join(sorted(kernels)), "driver": "tools/pvol_prof (tools/run_profiles.sh: bench.py scene and photon-map recipe, 640x360 at 256 spp)", "rays": rays,
         "counters": dict(agg),
         "per_ray": {k: v / rays for k, v in agg.items()},
         "l2_hit_rate": agg.get("TCC_HIT_sum", 0) / max(1.0, agg.get("TCC_HIT_sum", 0) + agg.get("TCC_MISS_sum", 0)),

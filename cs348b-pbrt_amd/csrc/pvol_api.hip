@@ -160,8 +160,7 @@ static float light_power_y(const pvol_scene *s, const pvol_light &l, float world
     return host_spec_y(s, p);
 }
 
-static int fill_shoot_scene(pvol_ctx *c, const pvol_scene *s) {
-    DevShootScene &H = c->hsh;
+static int fill_shoot_scene(const pvol_ctx *c, const pvol_scene *s, DevShootScene &H) {
     memset(&H, 0, sizeof(H));
     if (s->n_materials > PVOL_MAX_MATERIALS) return PVOL_E_UNSUPPORTED;
     if (s->n_materials && !s->materials) return PVOL_E_INVALID;
@@ -204,7 +203,7 @@ static int fill_shoot_scene(pvol_ctx *c, const pvol_scene *s) {
     H.nCausticWanted = c->params.n_caustic_photons;
     H.nIndirectWanted = c->params.n_indirect_photons;
     H.nVolumeWanted = c->params.n_volume_photons;
-    return ok(hipMemcpy(c->dsh, &H, sizeof(H), hipMemcpyHostToDevice)) ? PVOL_OK : PVOL_E_NO_DEVICE;
+    return PVOL_OK;
 }
 
 static void pad32(float *dst, const pvol_spectrum &s) {
@@ -218,36 +217,31 @@ int pvol_push_scene(pvol_ctx *c) {
 
 int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     if (!c || !s) return PVOL_E_INVALID;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    // Everything is validated and built into temporaries first; the context changes only when nothing can fail any more
+    // (a rejected scene leaves the previous one, including its density grid, in place).
     const pvol_volume &v = s->volume;
     if (v.kind != PVOL_VOLUME_NONE && v.kind != PVOL_VOLUME_HOMOGENEOUS && v.kind != PVOL_VOLUME_GRID && v.kind != PVOL_VOLUME_RAINBOW)
         return PVOL_E_UNSUPPORTED;
     if (s->n_lights > PVOL_MAX_LIGHTS || s->n_triangles > PVOL_MAX_TRIS) return PVOL_E_UNSUPPORTED;
     if ((s->n_lights && !s->lights) || (s->n_triangles && !s->triangles)) return PVOL_E_INVALID;
-    DevScene &h = c->hs;
-    // keep the photon-map fields, replace everything else
+    if (v.kind == PVOL_VOLUME_GRID && (!v.density || v.nx < 1 || v.ny < 1 || v.nz < 1)) return PVOL_E_INVALID;
+    for (uint32_t i = 0; i < s->n_lights; ++i) {
+        const int k = s->lights[i].kind;
+        if (k != PVOL_LIGHT_POINT && k != PVOL_LIGHT_SPOT && k != PVOL_LIGHT_DISTANT) return PVOL_E_UNSUPPORTED;
+    }
+    DevScene h = c->hs;   // keeps the photon-map fields, everything else is replaced
     h.volKind = v.kind;
     for (int i = 0; i < 3; ++i) { h.extLo[i] = v.extent_min[i]; h.extHi[i] = v.extent_max[i]; }
     memcpy(h.w2v, v.world_to_volume, sizeof(h.w2v));
     pad32(h.sigA, v.sigma_a); pad32(h.sigS, v.sigma_s); pad32(h.le, v.le);
     h.g = v.g;
     h.nx = v.nx; h.ny = v.ny; h.nz = v.nz;
-    if (c->dDensity) { hipFree(c->dDensity); c->dDensity = 0; }
     h.density = 0;
-    if (v.kind == PVOL_VOLUME_GRID) {
-        if (!v.density || v.nx < 1 || v.ny < 1 || v.nz < 1) return PVOL_E_INVALID;
-        size_t nb = sizeof(float) * (size_t)v.nx * v.ny * v.nz;
-        if (!ok(hipMalloc(&c->dDensity, nb))) return PVOL_E_NO_MEMORY;
-        if (!ok(hipMemcpy(c->dDensity, v.density, nb, hipMemcpyHostToDevice))) return PVOL_E_NO_DEVICE;
-        float md = 0.f;
-        for (size_t i = 0; i < nb / sizeof(float); ++i) md = std::max(md, v.density[i]);
-        c->maxDensity = md;
-        h.density = c->dDensity;
-    }
     h.nLights = (int)s->n_lights;
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const pvol_light &l = s->lights[i];
-        if (l.kind != PVOL_LIGHT_POINT && l.kind != PVOL_LIGHT_SPOT && l.kind != PVOL_LIGHT_DISTANT) return PVOL_E_UNSUPPORTED;
         DevLight &d = h.lights[i];
         d.kind = l.kind;
         for (int k = 0; k < 3; ++k) { d.pos[k] = l.pos[k]; d.dir[k] = l.dir[k]; }
@@ -283,12 +277,37 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         if (steps > 12000) return PVOL_E_LIMIT;
         h.maxSteps = ((int)steps + 63) & ~63;
     }
+    DevShootScene hsh;
     {
-        int rc = fill_shoot_scene(c, s);
+        int rc = fill_shoot_scene(c, s, hsh);
         if (rc != PVOL_OK) return rc;
     }
+    float *newDensity = 0;
+    float maxDensity = 1.f;
+    if (v.kind == PVOL_VOLUME_GRID) {
+        size_t nb = sizeof(float) * (size_t)v.nx * v.ny * v.nz;
+        if (!ok(hipMalloc(&newDensity, nb))) return PVOL_E_NO_MEMORY;
+        if (!ok(hipMemcpy(newDensity, v.density, nb, hipMemcpyHostToDevice))) { hipFree(newDensity); return PVOL_E_NO_DEVICE; }
+        float md = 0.f;
+        for (size_t i = 0; i < nb / sizeof(float); ++i) md = std::max(md, v.density[i]);
+        maxDensity = md;
+        h.density = newDensity;
+    }
+    // commit: kernels of earlier batches may still read the old scene and grid
+    if (!ok(hipDeviceSynchronize()) || !ok(hipMemcpy(c->dsh, &hsh, sizeof(hsh), hipMemcpyHostToDevice)) ||
+        !ok(hipMemcpy(c->ds, &h, sizeof(DevScene), hipMemcpyHostToDevice))) {
+        if (newDensity) hipFree(newDensity);
+        pvol_push_scene(c);   // best effort: put the device copy of the previous scene back
+        hipMemcpy(c->dsh, &c->hsh, sizeof(c->hsh), hipMemcpyHostToDevice);
+        return PVOL_E_NO_DEVICE;
+    }
+    if (c->dDensity) hipFree(c->dDensity);
+    c->dDensity = newDensity;
+    c->maxDensity = maxDensity;
+    c->hs = h;
+    c->hsh = hsh;
     c->haveScene = true;
-    return pvol_push_scene(c);
+    return PVOL_OK;
 }
 
 static void choose_grid(pvol_ctx *c, const float *p, uint32_t n) {
@@ -344,6 +363,7 @@ int pvol_upload_photons(pvol_ctx *c, const float *p, const float *wi, const floa
     if (!c) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
     if (n && (!p || !wi || !alpha)) return PVOL_E_INVALID;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
     hipDeviceSynchronize();
     pvol_free_photons(c);
@@ -402,6 +422,32 @@ static bool roulette_possible(const pvol_ctx *c) {
     return !(c->hs.stepSize * m * dens < 6.8f);
 }
 
+// Timing events: every batch records a pair on its launch stream.  Finished pairs are folded into the running sum and
+// recycled here, at the next launch and in pvol_kernel_time_ms, so the list stays short however many batches a caller
+// issues without ever asking for the time (the per-sample shim issues one per camera sample).  Caller holds c->mu.
+static bool harvest_events(pvol_ctx *c, bool wait) {
+    size_t keep = 0;
+    for (size_t i = 0; i < c->pending.size(); ++i) {
+        std::pair<hipEvent_t, hipEvent_t> p = c->pending[i];
+        // more than 64 batches in flight: wait for the oldest instead of growing
+        const bool block = wait || c->pending.size() - i > 64;
+        hipError_t q = block ? hipEventSynchronize(p.second) : hipEventQuery(p.second);
+        if (q == hipSuccess) {
+            float ms = 0.f;
+            if (ok(hipEventElapsedTime(&ms, p.first, p.second))) { c->timeMs += ms; c->launches += 1; }
+            c->pool.push_back(p);
+        } else if (q == hipErrorNotReady) {
+            c->pending[keep++] = p;
+        } else {
+            (void)hipGetLastError();
+            c->pool.push_back(p);
+            if (wait) { c->pending.erase(c->pending.begin(), c->pending.begin() + (i + 1 - keep)); return false; }
+        }
+    }
+    c->pending.resize(keep);
+    return true;
+}
+
 // `tile` != 0: the rays do not exist yet -- the tile kernel (pvol_tile_dev.h) generates them stream by stream
 // (LD sampler + camera) in front of the march, and takes the place of the RESOLVE pre-pass where one is needed.
 int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
@@ -419,6 +465,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     std::pair<hipEvent_t, hipEvent_t> ev;
     {
         std::lock_guard<std::mutex> g(c->mu);
+        harvest_events(c, false);
         if (!c->pool.empty()) { ev = c->pool.back(); c->pool.pop_back(); }
         else if (!ok(hipEventCreate(&ev.first)) || !ok(hipEventCreate(&ev.second))) return PVOL_E_NO_DEVICE;
     }
@@ -434,8 +481,9 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     if (sliced) {
         uint32_t maxRays = maxRaysPerStream;
         if (maxRays == 0) {   // device entry point: the stream table lives on the device
-            std::vector<pvol_stream> hs(nStreams);
-            if (!ok(hipMemcpy(hs.data(), dStreams, sizeof(pvol_stream) * (size_t)nStreams, hipMemcpyDeviceToHost))) return PVOL_E_NO_DEVICE;
+            std::vector<pvol_stream> hs(nStreams);   // read on the caller's stream: ordered behind whatever produced the table
+            if (!ok(hipMemcpyAsync(hs.data(), dStreams, sizeof(pvol_stream) * (size_t)nStreams, hipMemcpyDeviceToHost, stream)) ||
+                !ok(hipStreamSynchronize(stream))) return PVOL_E_NO_DEVICE;
             for (uint32_t i = 0; i < nStreams; ++i) maxRays = std::max(maxRays, hs[i].n_rays);
         }
         const bool grid = c->hs.volKind == PVOL_VOLUME_GRID;
@@ -509,15 +557,6 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     return ok(e) ? PVOL_OK : PVOL_E_NO_DEVICE;
 }
 
-int pvol_li_batch_device(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams,
-                         int outputKind, float *dOut, uint32_t *dDraws, void *hipStream) {
-    if (!c || (nRays && !dRays) || (nStreams && !dStreams) || (nRays && !dOut)) return PVOL_E_INVALID;
-    if (outputKind != PVOL_OUT_SPECTRAL && outputKind != PVOL_OUT_XYZ) return PVOL_E_INVALID;
-    if (!c->haveScene) return PVOL_E_NO_SCENE;
-    if (!nStreams) return PVOL_OK;
-    return launch(c, dRays, nRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, 0, (hipStream_t)hipStream);
-}
-
 static int check_errors(pvol_ctx *c) {
     DevCounters h;
     if (!ok(hipMemcpy(&h, c->dCounters, sizeof(h), hipMemcpyDeviceToHost))) return PVOL_E_NO_DEVICE;
@@ -529,10 +568,31 @@ static int check_errors(pvol_ctx *c) {
     return PVOL_OK;
 }
 
+int pvol_li_batch_device(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams,
+                         int outputKind, float *dOut, uint32_t *dDraws, void *hipStream) {
+    if (!c || (nRays && !dRays) || (nStreams && !dStreams) || (nRays && !dOut)) return PVOL_E_INVALID;
+    if (outputKind != PVOL_OUT_SPECTRAL && outputKind != PVOL_OUT_XYZ) return PVOL_E_INVALID;
+    if (!c->haveScene) return PVOL_E_NO_SCENE;
+    if (!nStreams) return PVOL_OK;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    return launch(c, dRays, nRays, dStreams, nStreams, outputKind, dOut, dDraws, 0, 0, 0, 0, (hipStream_t)hipStream);
+}
+
+int pvol_check_errors(pvol_ctx *c) {
+    if (!c) return PVOL_E_INVALID;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
+    if (!ok(hipSetDevice(c->params.device)) || !ok(hipDeviceSynchronize())) return PVOL_E_NO_DEVICE;
+    return check_errors(c);
+}
+
 static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_stream *streams, uint32_t nStreams, int outputKind,
                       float *out, uint32_t *draws, uint32_t *mtState, int transOnly) {
     if (!c || (nRays && (!rays || !out)) || (nStreams && !streams)) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
+    // VolumeIntegrator::Li() is called by every SamplerRendererTask thread at once (samplerrenderer.cpp:247): calls on one
+    // context are serialised here, from the upload to the copy-back (the launches share the context's scratch)
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
     uint32_t maxRays = 1;
     {   // streams must partition the ray array in order (every ray belongs to exactly one stream)
@@ -560,7 +620,7 @@ static int host_batch(pvol_ctx *c, const pvol_ray *rays, uint32_t nRays, pvol_st
         if (!good) rc = PVOL_E_NO_DEVICE;
     }
     if (rc == PVOL_OK) rc = launch(c, dRays, nRays, dStreams, nStreams, transOnly ? PVOL_OUT_SPECTRAL : outputKind, dOut, dDraws, dState, dState, transOnly, maxRays, 0);
-    if (rc == PVOL_OK && !ok(hipDeviceSynchronize())) rc = PVOL_E_NO_DEVICE;
+    if (rc == PVOL_OK && !ok(hipStreamSynchronize(0))) rc = PVOL_E_NO_DEVICE;
     if (rc == PVOL_OK) rc = check_errors(c);
     if (rc == PVOL_OK) {
         if (transOnly) {
@@ -639,13 +699,7 @@ const char *pvol_march_kernel_name(pvol_ctx *c) { return c ? c->lastKernel : "";
 int pvol_kernel_time_ms(pvol_ctx *c, double *avgMs, uint64_t *launches, int reset) {
     if (!c || !avgMs) return PVOL_E_INVALID;
     std::lock_guard<std::mutex> g(c->mu);
-    for (auto &p : c->pending) {
-        if (!ok(hipEventSynchronize(p.second))) return PVOL_E_NO_DEVICE;
-        float ms = 0.f;
-        if (ok(hipEventElapsedTime(&ms, p.first, p.second))) { c->timeMs += ms; c->launches += 1; }
-        c->pool.push_back(p);
-    }
-    c->pending.clear();
+    if (!harvest_events(c, true)) return PVOL_E_NO_DEVICE;
     *avgMs = c->launches ? c->timeMs / (double)c->launches : 0.0;
     if (launches) *launches = c->launches;
     if (reset) { c->timeMs = 0; c->launches = 0; }

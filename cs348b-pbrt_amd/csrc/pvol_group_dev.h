@@ -255,7 +255,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
             bool bad = false;
             int maxN = nS;
             for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
-            if (STATS) wc.rays += __popcll(__ballot(have));
+            wc.rays += __popcll(__ballot(have));
             for (int j = 0; j < maxN; ++j) {
                 const bool act = j < nS;
                 const V3 p = o + d * tcur;
@@ -313,7 +313,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         ++uCount;
                     }
                 }
-                if (STATS) { wc.steps += __popcll(__ballot(act)); wc.unocc += __popcll(__ballot(lit)); }
+                wc.steps += __popcll(__ballot(act));
+                if (STATS) wc.unocc += __popcll(__ballot(lit));
                 // ---- k-NN gather of the group
                 float acc[32];
 #pragma unroll

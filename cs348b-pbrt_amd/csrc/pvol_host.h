@@ -76,7 +76,11 @@ struct pvol_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t> > pool;
     double timeMs;
     uint64_t launches;
-    std::mutex mu;
+    std::mutex mu;       // event lists only
+    // One batch at a time per context: the launches of a batch share dWords / dRecords / dState / dCounters and the
+    // deferred-lookup list.  Host entry points hold it from upload to copy-back (VolumeIntegrator::Li is called from every
+    // SamplerRendererTask thread at once, samplerrenderer.cpp:247); device entry points hold it while they enqueue.
+    std::recursive_mutex apiMu;
     // resolve/replay scratch (grown on demand)
     unsigned char *dRecords = 0;
     size_t recBytes = 0;
@@ -86,6 +90,7 @@ struct pvol_ctx {
     DevShootScene hsh;
     DevShootScene *dsh;
     uint64_t shootStats[12];
+    double prepSeconds[2] = {0.0, 0.0};   // last pvol_preprocess: shooting (all rounds + merges), search-structure build
     // tile driver work buffers (grown on demand, pvol_tile.hip)
     void *dTile[6] = {0, 0, 0, 0, 0, 0};
     size_t tileBytes[6] = {0, 0, 0, 0, 0, 0};

@@ -549,7 +549,7 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
     ray.mint = pr.mint;
     ray.maxt = pr.maxt;
     f4 Lv = mk4(0.f), Tr = mk4(1.f);
-    if (STATS) ++wc.rays;
+    ++wc.rays;   // rays and march steps are counted in every build (wave-uniform adds, one atomic per wave at the end)
     if (A.transmittanceOnly) {
         *TrOut = transmittance<RNGON>(S, ray, rng, sigT, lane);
         *LvOut = Lv;
@@ -608,7 +608,7 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
         V3 cDvInv = v3(0.f, 0.f, 0.f);
         triPre.valid = false;
         for (int i = 0; i < nEff; ++i, t0 += step) {
-            if (STATS) ++wc.steps;
+            ++wc.steps;
             pPrev = p;
             p = ray.o + ray.d * t0;
             const V3 pv = xform_point(S.w2v, p);
@@ -791,7 +791,7 @@ __device__ int march_ray_blocked(const DevScene &S, const LiArgs &A, const pvol_
     bool hit = vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
     int nSamples = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
     if (MODE == MODE_REPLAY && hit && nSamples > S.maxSteps) return 2;   // march_ray reports it
-    if (STATS) ++wc.rays;
+    ++wc.rays;
     int nEff = nSamples;
     bool killed = false;
     if (MODE == MODE_REPLAY) { nEff = (int)rec.hdr[0]; killed = (rec.hdr[1] & 1u) != 0u; }
@@ -892,7 +892,8 @@ __device__ int march_ray_blocked(const DevScene &S, const LiArgs &A, const pvol_
             }
             // draws of the block: one tau() offset per step + one per lit shadow ray (roulette excluded above)
             rng.draws += (unsigned long long)cnt + (unsigned long long)__popcll(__ballot(lit));
-            if (STATS) { wc.steps += cnt; wc.unocc += __popcll(__ballot(lit)); }
+            wc.steps += cnt;
+            if (STATS) wc.unocc += __popcll(__ballot(lit));
             // ---- serial part: spectral arithmetic + gather, one step at a time
             for (int j = 0; j < cnt; ++j) {
                 const float lenJ = lane_f(lenStep, j);
@@ -966,9 +967,11 @@ __device__ __forceinline__ void write_outputs(const DevScene &S, const LiArgs &A
 
 template <bool STATS>
 __device__ __forceinline__ void flush_counters(DevCounters *c, const WaveCounters &wc, unsigned long long t0, int lane) {
+    if (lane == 0) {   // Li() calls and march steps (= photon lookups): always, they feed the bench's per-sample figures
+        if (wc.rays) atomicAdd(&c->nRays, wc.rays);
+        if (wc.steps) atomicAdd(&c->nSteps, wc.steps);
+    }
     if (STATS && lane == 0) {
-        atomicAdd(&c->nRays, wc.rays);
-        atomicAdd(&c->nSteps, wc.steps);
         atomicAdd(&c->nShadowUnoccluded, wc.unocc);
         atomicAdd(&c->nTested, wc.tested);
         atomicAdd(&c->nKept, wc.kept);

@@ -4,6 +4,7 @@
 // abort, photonshooter.cpp:280-356), then the search-structure build.
 #include <math.h>
 #include <string.h>
+#include <chrono>
 #include <algorithm>
 #include <vector>
 
@@ -76,6 +77,7 @@ bool grow_map(Buffers &B, size_t used, size_t need) {
 extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     if (!c || n_tasks == 0 || n_tasks > 65536) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
     hipDeviceSynchronize();
     pvol_free_photons(c);
@@ -86,6 +88,8 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     int rc = pvol_push_scene(c);
     if (rc != PVOL_OK) return rc;
 
+    const auto tShoot0 = std::chrono::steady_clock::now();
+    c->prepSeconds[0] = c->prepSeconds[1] = 0.0;
     const uint32_t T = n_tasks;
     const uint32_t blockSize = 4096;
     // room for one block of one task: spectral splitting stores up to ~3 photons per path.  With very many
@@ -183,6 +187,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     c->shootStats[0] = st[0]; c->shootStats[1] = st[1]; c->shootStats[2] = st[2]; c->shootStats[3] = st[3]; c->shootStats[4] = st[4];
     c->shootStats[5] = st[5]; c->shootStats[6] = nVolume; c->shootStats[7] = nCaustic; c->shootStats[8] = nDirect; c->shootStats[9] = nIndirect;
     c->shootStats[10] = st[6]; c->shootStats[11] = nshot;
+    c->prepSeconds[0] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tShoot0).count();
     if (rc == PVOL_OK && st[7] != 0) rc = PVOL_E_LIMIT;   // a frame stack or block buffer overflowed: never silently drop photons
     if (rc != PVOL_OK || nVolume == 0) {
         B.release(false);
@@ -193,7 +198,17 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     if (!ok(hipMemcpy(hostP.data(), B.p, sizeof(float) * 3 * nVolume, hipMemcpyDeviceToHost))) { B.release(false); return PVOL_E_NO_DEVICE; }
     c->dRawP = B.p; c->dRawWi = B.wi; c->dRawAlpha = B.alpha;
     B.release(true);
-    return pvol_finish_map(c, (uint32_t)nVolume, hostP.data());
+    const auto tBuild0 = std::chrono::steady_clock::now();
+    rc = pvol_finish_map(c, (uint32_t)nVolume, hostP.data());
+    hipDeviceSynchronize();
+    c->prepSeconds[1] = std::chrono::duration<double>(std::chrono::steady_clock::now() - tBuild0).count();
+    return rc;
+}
+
+extern "C" int pvol_get_preprocess_seconds(pvol_ctx *c, double *out2) {
+    if (!c || !out2) return PVOL_E_INVALID;
+    out2[0] = c->prepSeconds[0]; out2[1] = c->prepSeconds[1];
+    return PVOL_OK;
 }
 
 extern "C" int pvol_get_shoot_stats(pvol_ctx *c, uint64_t *out12) {

@@ -216,6 +216,7 @@ extern "C" int pvol_render_tasks_device(pvol_ctx *c, const pvol_camera *camera, 
     if (smp->scatter_index >= smp->n1d_count || smp->n1d[smp->scatter_index] != 1) return PVOL_E_INVALID;
     if (smp->n_tasks == 0 || smp->x_end < smp->x_start || smp->y_end < smp->y_start) return PVOL_E_INVALID;
     for (uint32_t i = 0; i < nTaskIds; ++i) if (taskIds[i] >= smp->n_tasks) return PVOL_E_INVALID;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);   // the work buffers and launch scratch live in the context
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
     hipStream_t stream = (hipStream_t)hipStream;
 

@@ -58,6 +58,8 @@ def lib():
         L.pvol_kernel_time_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]
         L.pvol_get_shoot_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.pvol_march_kernel_name.argtypes = [C.c_void_p]
+        L.pvol_check_errors.argtypes = [C.c_void_p]
+        L.pvol_get_preprocess_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.pvol_march_kernel_name.restype = C.c_char_p
         L.pvol_gaussian_filter_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
         L.pvol_gaussian_filter_table.restype = None
@@ -78,7 +80,7 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
            "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats",
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
-           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name"]
+           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -127,6 +129,16 @@ class PhotonVolume:
 
     def preprocess(self, n_tasks=1):
         _check(lib().pvol_preprocess(self._h, n_tasks), "pvol_preprocess")
+
+    def preprocess_times(self):
+        """(shoot seconds, search-structure build seconds) of the last preprocess()."""
+        v = (C.c_double * 2)()
+        _check(lib().pvol_get_preprocess_seconds(self._h, v), "pvol_get_preprocess_seconds")
+        return float(v[0]), float(v[1])
+
+    def check_errors(self):
+        """Raises PvolError(PVOL_E_LIMIT) if a batch enqueued through a device entry point hit a kernel limit."""
+        _check(lib().pvol_check_errors(self._h), "pvol_check_errors")
 
     def shoot_stats(self):
         v = (C.c_uint64 * 12)()

@@ -260,6 +260,11 @@ int pvol_preprocess(pvol_ctx *ctx, uint32_t n_tasks);
  * children, nshot. */
 int pvol_get_shoot_stats(pvol_ctx *ctx, uint64_t *out12);
 
+/* Wall-clock seconds of the last pvol_preprocess: out[0] the shooting rounds and merges
+ * (PhotonShootingTask::Run, photonshooter.cpp:232-357), out[1] the device search-structure build that replaces
+ * the kd-tree construction (photonshooter.cpp:502-503, core/kdtree.h:100-147). */
+int pvol_get_preprocess_seconds(pvol_ctx *ctx, double *out2);
+
 /* Number of photons in the current volume map. */
 int pvol_photon_count(pvol_ctx *ctx, uint32_t *n);
 /* Copies the current map back (same layout as pvol_upload_photons); capacity in photons. */
@@ -282,9 +287,17 @@ int pvol_li_batch_device(pvol_ctx *ctx, const pvol_ray *d_rays, uint32_t n_rays,
                          int output_kind, float *d_out, uint32_t *d_draws,
                          void *hip_stream);
 
+/* Device-side error flags of the batches enqueued so far (pvol_li_batch_device, pvol_render_tasks_device): waits
+ * for the device and returns PVOL_E_LIMIT if a ray needed more march steps than the kernels' record/LDS plan holds
+ * (such a ray's output is zero, never a guess), clearing the flag.  The host entry points check this themselves. */
+int pvol_check_errors(pvol_ctx *ctx);
+
 /* Single call with the caller's live RNG (the per-sample shim behind
  * VolumeIntegrator::Li): mt[624] / *mti are core/rng.h:57-58 narrowed to 32 bits and are
- * advanced exactly as the reference would advance them.  Lv, T: 30 floats each. */
+ * advanced exactly as the reference would advance them.  Lv, T: 30 floats each.
+ * Thread-safe: concurrent calls on one context (every SamplerRendererTask thread calls
+ * VolumeIntegrator::Li, samplerrenderer.cpp:247) are serialised inside the library, as are all
+ * other host-pointer entry points. */
 int pvol_li(pvol_ctx *ctx, const pvol_ray *ray, uint32_t *mt, int32_t *mti,
             float *Lv, float *T);
 

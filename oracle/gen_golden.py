@@ -149,7 +149,18 @@ def render_case(tag, scene_name, photons, xres, yres, spp, ntasks, tasks=None, *
     cap(*args)
 
 
+def main_hg():
+    """Row a16 (PhaseHG with g != 0, core/volume.cpp:150-154): the volumescene with `"float g" 0.6` on the Volume."""
+    cap("scene", "volumescene_hg", os.path.join(GOLD, "scene_volumescene_hg.bin"))
+    cap("units", "volumescene_hg", os.path.join(GOLD, "ref_units_volumescene_hg.bin"))
+    shoot("volumescene_hg", 6000, "vhg")          # the shooter's scattering weight alpha *= p(wo, wi) / pdf now varies
+    make_case("vhg", "volumescene_hg", 12, 10, 3, 11, photons="vhg")
+    make_case("vhg_k20", "volumescene_hg", 8, 8, 2, 12, photons="vhg", overrides={"n_used": 20, "max_dist": 0.3})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "hg":   # only the fixtures added in round 2
+        return main_hg()
     os.makedirs(GOLD, exist_ok=True)
     cap("tables", os.path.join(GOLD, "ref_tables.bin"))
     for s in ["volumescene_h", "volumescene_rainbow", "volumescene_grid16", "pinkfloyd", "shootbench"]:
@@ -177,6 +188,7 @@ def main():
     render_case("vh64", "volumescene_h", "vh", 10, 6, 64, 4, tasks=[0, 2, 3])
     render_case("grid16", "volumescene_grid16", "grid16", 16, 10, 2, 4)
     render_case("pf", "pinkfloyd", "pf", 16, 16, 4, 4, nused=50, maxdist=0.25)
+    main_hg()
 
 
 if __name__ == "__main__":

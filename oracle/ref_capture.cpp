@@ -169,9 +169,10 @@ static void finish(BuiltScene &B) {
 }
 
 static VolumeRegion *makeVolume(BuiltScene &B, const Transform &ctm, const char *kind, const float p0[3], const float p1[3],
-                                float sa, float ss, int gridN = 0) {
+                                float sa, float ss, int gridN = 0, float g = 0.f) {
     ParamSet ps;
     float rgbA[3] = {sa, sa, sa}, rgbS[3] = {ss, ss, ss};
+    if (g != 0.f) ps.AddFloat("g", &g, 1);   // Henyey-Greenstein asymmetry (volumes/homogeneous.cpp:44)
     ps.AddRGBSpectrum("sigma_a", rgbA, 3);
     ps.AddRGBSpectrum("sigma_s", rgbS, 3);
     Point a(p0[0], p0[1], p0[2]), b(p1[0], p1[1], p1[2]);
@@ -237,7 +238,7 @@ static const int kPrismIdx[24] = {0, 1, 2, 0, 2, 3, 1, 4, 5, 1, 5, 2, 0, 4, 1, 2
 
 // projectScene/volumescene_png.pbrt; `volKind` swaps the Volume statement, `gridN` > 0
 // makes the synthetic config-4 variant.
-static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN) {
+static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN, float g = 0.f) {
     B.stepSize = .15f; B.nUsed = 50; B.maxDist = 0.5f; B.nVolumePhotons = 5000;
     B.shooterStep = 0.1f; B.maxPhotonDepth = 5; B.nCaustic = 5000; B.nIndirect = 0; B.finalGather = 1;
     B.xres = B.yres = 300; B.spp = 1; B.fov = 70.f;
@@ -245,7 +246,7 @@ static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN) {
     B.camToWorld = Inverse(camCtm);
     Transform ctm = Transform() * Translate(Vector(0, -0.5f, 3.5f));
     float p0[3] = {-10, 0, -5}, p1[3] = {5, 5, 5};
-    B.volume = makeVolume(B, ctm, volKind, p0, p1, .05f, .1f, gridN);
+    B.volume = makeVolume(B, ctm, volKind, p0, p1, .05f, .1f, gridN, g);
     float from[3] = {0, 3, 0}, to[3] = {0, 2, 5};
     addDistant(B, ctm, from, to, 150.f);
     int m = addMatte(B, .01f, .01f, .01f);
@@ -308,6 +309,7 @@ static void buildShootBench(BuiltScene &B) {
 
 static bool buildByName(BuiltScene &B, const std::string &name) {
     if (name == "volumescene_h") buildVolumeScene(B, "homogeneous", 0);
+    else if (name == "volumescene_hg") buildVolumeScene(B, "homogeneous", 0, 0.6f);   // anisotropic phase function (row a16)
     else if (name == "volumescene_rainbow") buildVolumeScene(B, "rainbow", 0);
     else if (name == "volumescene_grid16") buildVolumeScene(B, "grid", 16);
     else if (name == "volumescene_grid128") buildVolumeScene(B, "grid", 128);

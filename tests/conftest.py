@@ -51,6 +51,8 @@ LI_CASES = {
     "grid16": ("volumescene_grid16", "grid16"),
     "pf": ("pinkfloyd", "pf"),
     "pf_k50": ("pinkfloyd", "pf"),
+    "vhg": ("volumescene_hg", "vhg"),        # Henyey-Greenstein g = 0.6 (row a16): phase_hg in L_d and in the flux sum (wi4 reads)
+    "vhg_k20": ("volumescene_hg", "vhg"),
 }
 TRANS_CASES = {"trans_vh": "volumescene_h", "trans_grid16": "volumescene_grid16"}
 

@@ -98,8 +98,10 @@ def test_group_kernel_matches_oracle_on_a_dense_map(pvol, orc, vh_map, scene_nam
         err = rel_l2(got[:, :30], ref[:, :30], floor=1e-12)
         assert err.max() <= TOL, "rel L2 %.3g at ray %d" % (err.max(), int(err.argmax()))
         np.testing.assert_allclose(got[:, 30:], ref[:, 30:], rtol=1e-5, atol=1e-7)
-        # the bucket plan, not the fallback, served the bulk of the lookups (each wave's first group starts cold)
-        assert st["n_kept"] > 0.5 * st["n_steps"], st
+        # the bucket plan, not the exact fallback, served the lookups: at most 5 % of them were redone (each wave's first
+        # group starts cold), and the plan's flux sums took k photons for at least 90 % of the march steps
+        assert st["n_guess_retries"] <= 0.05 * st["n_steps"], st
+        assert st["n_kept"] >= 0.8 * p.n_used * (st["n_steps"] - st["n_guess_retries"] - st["n_lookups_lt10"]), st
         # one stream position per render task, all draws accounted for
         o_end = streams.copy()
         o.li_batch(rays, o_end)
@@ -156,5 +158,49 @@ def test_ragged_batches_and_rays_that_miss(pvol, orc, vh_map):
             assert (gd == rd).all()
             assert rel_l2(got[:, :30], ref[:, :30], floor=1e-12).max() <= TOL
             np.testing.assert_allclose(got[:, 30:], ref[:, 30:], rtol=1e-5, atol=1e-7)
+    finally:
+        pv.close()
+
+
+def test_headline_shape_256spp_on_a_million_photon_map(pvol, orc):
+    """The configuration bench.py quotes (C2: 1280x720, 256 spp, 4096 render tasks, >= 1 M photons shot on the device with
+    16384 virtual tasks) through the entry point it uses (pvol_render_tasks_device: tile pre-pass, li_group_kernel with its
+    512-ray chunks = two pixels at 256 spp, film), for a handful of WHOLE render tasks against the oracle's
+    SamplerRendererTask loop on the same downloaded map: per-sample XYZ <= 1e-4 rel. L2, every stream position exact."""
+    import torch
+    s = load_scene("volumescene_h")
+    pv, p, photons = _dense_map(pvol, s, 1000000, 16384)
+    try:
+        assert pv.photon_count() >= 1000000
+        xres, yres, spp, ntasks = 1280, 720, 256, 4096
+        cam = abi.perspective_camera(float(s["camera.fov"][0]), xres, yres, s["camera.c2w"])
+        film = abi.make_film(xres, yres, pvol.gaussian_filter_table())
+        smp = abi.make_sampler(xres, yres, spp, ntasks)
+        tasks = np.array([37, 1500, 2050, 4000], np.uint32)   # frame corner (apron, rays that miss), middle rows, last row
+        n = pvol.render_sample_count(smp, tasks)
+        assert n > 200000
+        dev = torch.device("cuda:0")
+        pixels = torch.zeros((yres, xres, 4), dtype=torch.float32, device=dev)
+        xyz = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        streams = torch.zeros((len(tasks), 32), dtype=torch.uint8, device=dev)
+        pv.enable_stats(True)
+        pv.stats(reset=True)
+        pv.render_tasks(cam, film, smp, tasks, pixels.data_ptr(), abi.RenderDebug(0, 0, xyz.data_ptr(), streams.data_ptr()))
+        torch.cuda.synchronize()
+        pv.check_errors()
+        assert pv.march_kernel_name() == "li_group_kernel"
+        st = pv.stats()
+        o = orc.Oracle(abi.SceneHolder(s), p)
+        o.set_photons(*photons)
+        ref = orc.render_tasks(o, cam, film, smp, tasks, n_threads=8)
+        end = streams.cpu().numpy().view(abi.STREAM_DTYPE).reshape(-1)["end_draw"]
+        np.testing.assert_array_equal(end, ref["end_draws"])
+        a, b = xyz.cpu().numpy().astype(np.float64), ref["xyzT"].astype(np.float64)
+        scale = np.abs(b[:, :3]).max()
+        err = np.linalg.norm(a[:, :3] - b[:, :3], axis=1) / np.maximum(np.linalg.norm(b[:, :3], axis=1), 1e-6 * scale)
+        assert err.max() <= TOL, "per-sample XYZ rel L2 %.3g at sample %d" % (err.max(), int(err.argmax()))
+        np.testing.assert_allclose(a[:, 3], b[:, 3], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(pixels.cpu().numpy(), ref["pixels"], rtol=1e-4, atol=1e-5 * np.abs(ref["pixels"]).max())
+        assert st["n_guess_retries"] <= 0.05 * st["n_steps"], st
     finally:
         pv.close()

@@ -110,6 +110,71 @@ def test_single_call_shim_advances_the_callers_rng(pvol, orc):
     pv.close()
 
 
+def test_concurrent_single_calls_are_serialised(pvol, orc):
+    """VolumeIntegrator::Li is called from every SamplerRendererTask thread at once (samplerrenderer.cpp:247): several host
+    threads call pvol_li on ONE context, each with its own live MT19937 state.  pf_k50 has two lights, so every call takes
+    the resolve + replay path whose records / state / counters live in the context -- the calls must not interleave."""
+    import threading
+    s, p, rays, streams, c = load_li_case("pf_k50")
+    ph = load_photons("pf")
+    pv = _ctx(pvol, s, p, ph)
+    o = orc.Oracle(abi.SceneHolder(s), p)
+    o.set_photons(*ph)
+    n_threads, per = 4, 6
+    refs, got = {}, {}
+    for t in range(n_threads):
+        sub = rays[t * per:(t + 1) * per].copy()
+        sub["rng_skip"] = 0
+        st = abi.make_streams(np.array([100 + t], np.uint32), np.array([per], np.uint32))
+        refs[t] = o.li_batch(sub, st)[0]
+
+    def mt_seeded(seed):
+        mt = np.zeros(624, np.uint32)
+        mt[0] = seed
+        for i in range(1, 624):
+            mt[i] = (1812433253 * (int(mt[i - 1]) ^ (int(mt[i - 1]) >> 30)) + i) & 0xffffffff
+        return mt
+
+    def worker(t):
+        mt, mti = mt_seeded(100 + t), 624
+        outs = []
+        for k in range(per):
+            ray = rays[t * per + k:t * per + k + 1].copy()
+            ray["rng_skip"] = 0
+            Lv, T, mti = pv.li_single(ray, mt, mti)
+            outs.append(np.concatenate([Lv, T]))
+        got[t] = np.stack(outs)
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for t in range(n_threads):
+        floor = 1e-6 * float(np.abs(refs[t][:, :30]).max())
+        assert rel_l2(got[t][:, :30], refs[t][:, :30], floor=floor).max() <= TOL, t
+        np.testing.assert_allclose(got[t][:, 30:], refs[t][:, 30:], rtol=1e-5, atol=1e-7)
+    pv.close()
+
+
+def test_a_rejected_scene_leaves_the_previous_one_in_place(pvol, orc):
+    """pvol_set_scene validates everything before it touches the context: after a failed call the old scene (and its
+    density grid) still renders."""
+    import ctypes as C
+    s, p, rays, streams, c = load_li_case("grid16")
+    ph = load_photons("grid16")
+    pv = _ctx(pvol, s, p, ph)
+    before, _ = pv.li(rays, streams.copy())
+    bad = abi.SceneHolder(s)
+    bad.scene.lights[0].kind = 77                      # unsupported light kind, detected after the volume was looked at
+    with pytest.raises(pvol.PvolError) as e:
+        pv.set_scene(bad)
+    assert e.value.status == abi.PVOL_E_UNSUPPORTED
+    after, _ = pv.li(rays, streams.copy())
+    assert (before == after).all()
+    pv.close()
+
+
 def test_gather_properties_at_scale(pvol, orc):
     """Size-independent properties on a map too big for the oracle to march in seconds:
     linearity in alpha, idempotence, and agreement with the oracle on a sampled subset of rays."""

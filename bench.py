@@ -240,9 +240,13 @@ def gpu_parity(torch, dev, pv, abi, cam, film, smp, first, stream):
     spp = smp.pixel_samples
     gp, rp = got[:, :3].reshape(-1, spp, 3).mean(1), ref[:, :3].reshape(-1, spp, 3).mean(1)
     perr = np.linalg.norm(gp - rp, axis=1) / np.maximum(np.linalg.norm(rp, axis=1), 1e-6 * scale)
-    return {"samples": int(n), "tasks": int(len(tasks)), "max_rel_l2_per_sample": float(err.max()), "max_rel_l2_per_pixel": float(perr.max()),
-            "rng_end_positions_equal": bool((end == first["end_draws"]).all()), "tolerance": 1e-4,
-            "ok": bool(err.max() <= 1e-4 and (end == first["end_draws"]).all())}
+    # bar (north_star): <= 1e-4 relative L2 per PIXEL, stream positions exact.  Per sample the figure is reported too: it
+    # exceeds 1e-4 only where two photons tie exactly for the k-th place of a lookup (the reference keeps the one its kd-tree
+    # traversal met first; see tests/test_gpu_group.py::test_headline_shape_256spp_on_a_million_photon_map)
+    return {"samples": int(n), "tasks": int(len(tasks)), "max_rel_l2_per_pixel": float(perr.max()), "max_rel_l2_per_sample": float(err.max()),
+            "samples_above_1e-4": int((err > 1e-4).sum()),
+            "rng_end_positions_equal": bool((end == first["end_draws"]).all()), "tolerance_per_pixel": 1e-4,
+            "ok": bool(perr.max() <= 1e-4 and (end == first["end_draws"]).all())}
 
 
 def spawn_ranks(n):
@@ -455,7 +459,7 @@ def main():
             res["cpu_baseline"] = cpu
         if first is not None:
             res["parity"] = gpu_parity(torch, dev, pv, abi, cam, film, smp, first, stream)
-            res["parity_max_rel_l2"] = res["parity"]["max_rel_l2_per_sample"]
+            res["parity_max_rel_l2"] = res["parity"]["max_rel_l2_per_pixel"]
             if not res["parity"]["ok"]:
                 rc = 3
         # ---- roofline of the dominant kernel.  What binds it is VALU issue, not HBM (measured traffic is ~2 % of the 8 TB/s

@@ -79,7 +79,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     { const char *fs = getenv("PVOL_FORCE_SEQ"); c->forceSeq = fs && fs[0] == '1'; }
     { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
     { const char *nl = getenv("PVOL_NO_LITE"); c->noLite = nl && nl[0] == '1'; }
-    { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 8; }
+    { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 12; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
@@ -123,6 +123,7 @@ void pvol_destroy(pvol_ctx *c) {
     if (c->dDensity) hipFree(c->dDensity);
     if (c->dRecords) hipFree(c->dRecords);
     if (c->dState) hipFree(c->dState);
+    if (c->dDefer) hipFree(c->dDefer);
     for (int i = 0; i < 6; ++i) if (c->dTile[i]) hipFree(c->dTile[i]);
     if (c->ds) hipFree(c->ds);
     if (c->dsh) hipFree(c->dsh);
@@ -337,6 +338,8 @@ static void choose_grid(pvol_ctx *c, const float *p, uint32_t n) {
     h.ringMax = (int)ceil(maxDist / h.cellSize);
     if (h.ringMax > PVOL_MAX_RING) h.ringMax = PVOL_MAX_RING;
     if (h.ringMax < 1) h.ringMax = 1;
+    // radius^2 of the ball that holds nUsed photons at the map's mean density: where a lookup with nothing better starts
+    h.rkEstimate = (float)pow((double)c->params.n_used * vol / ((double)std::max(1u, n) * 4.18879020478639), 2.0 / 3.0);
 }
 
 int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions) {
@@ -508,7 +511,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         a.records = c->dRecords; a.recStride = (uint32_t)stride; a.sliceM = sliceM; a.state = c->dState;
         a.liteResolve = (!tile && !c->noLite && !roulette_possible(c)) ? 1 : 0;
     }
-    if (par) hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
+    if (par) hipMemsetAsync(c->dWords, 0, 3 * sizeof(uint32_t), stream);
     if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel
         a.sliceK = 0; a.sliceM = 0xffffffc0u; a.state = 0;
         if (!ok(pvol_launch_tile(&a, tile, false, pvol_tile_lds_bytes(0, tile->spp, false), c->hs.candCap, stream))) return PVOL_E_NO_DEVICE;
@@ -523,7 +526,18 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         if (group) {
             unsigned long long gchunks = ((unsigned long long)nRays + 511ull) / 512ull;   // GRP_CH rays per chunk
             uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
-            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, stream);
+            // room for the lookups the bucket plan hands over (a fraction of a percent of ~40 per ray on C2); a list that
+            // overflows raises needSeq and the batch is redone sequentially, never truncated
+            const size_t wantDefer = (size_t)nRays / 4 + 65536;
+            if (wantDefer > c->deferCap) {
+                hipStreamSynchronize(stream);   // an earlier batch may still read the old list
+                if (c->dDefer) hipFree(c->dDefer);
+                c->dDefer = 0; c->deferCap = 0;
+                if (!ok(hipMalloc(&c->dDefer, wantDefer * sizeof(DeferRec)))) return PVOL_E_NO_MEMORY;
+                c->deferCap = wantDefer;
+            }
+            a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
+            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, (uint32_t)c->nCU * 8u, stream);
             c->lastKernel = "li_group_kernel";
         } else {
             c->lastKernel = "li_par_kernel";

@@ -66,6 +66,17 @@ struct DevScene {
     // LDS plan (bytes offsets are derived in the kernel from these)
     int32_t candCap;          // candidate list capacity (multiple of 64, >= nUsed + 128)
     int32_t maxSteps;         // upper bound of march steps per ray (lightNum array length)
+    float rkEstimate;         // k-th nearest distance^2 expected at the map's mean density (first guess of a cold lookup)
+};
+
+// One lookup li_group_kernel hands to li_fixup_kernel (pvol_group_dev.h)
+struct DeferRec {
+    uint32_t ray;
+    float px, py, pz;
+    float kRem;       // -log2(e) * optical length behind the step
+    float stepD;      // step length x density factor
+    float guess;      // a k-th distance^2 nearby, 0 = none
+    uint32_t pad;
 };
 
 // What only the photon shooter reads (core/photonshooter.cpp): surface materials, emission frames,

@@ -5,32 +5,45 @@
 // hundredths of a unit of each other -- and share one candidate search:
 //   1. STAGE   the photons within sqrt(T) + rho of the group's centre (T = guessed radius^2, rho = spread of the
 //              query points) are found cooperatively in the cell grid and parked in LDS ("LDS-staged bucket");
-//   2. SELECT  every lane finds ITS exact k-th smallest DistanceSquared over the bucket: a histogram pass over
-//              [T/4, T) (byte counters in LDS, one column per lane) locates the bin of the k-th, a second pass keeps
-//              that bin's few values sorted in registers;
-//   3. FLUX    one more pass adds the alpha row of every bucket photon (wave-uniform address: broadcast loads)
-//              into the per-lane 30-bin accumulators of the lanes whose k-NN set contains it.
-// All three passes evaluate kdtree.h:180's DistanceSquared per lane in the reference's operation order, so the
-// k-NN sets are the reference's; only the order of the flux additions differs (as in lphoton).  A lane whose
-// lookup does not fit the plan (guess too small or too large, crowded bin, bucket overflow) is redone by the
-// wave-cooperative lphoton(), which is always exact.  Spectra live as 30 registers per lane.
+//   2. SELECT  every lane finds ITS exact k-th smallest DistanceSquared over the bucket.  Pass 1 histograms the
+//              values over [0, T) into 64 four-bit counters per lane (LDS, one column per lane) and a prefix scan
+//              finds the bin b* of the k-th.  Pass 2 leaves, per lane, one BIT per bucket slot: "bin < b*" (a member
+//              for sure) and "bin <= b*".  The few photons of bin b* itself are then looked at individually: their
+//              values sorted in registers give the exact k-th distance, ties are taken in bucket order, and their
+//              member bits are added.
+//   3. FLUX    for every bucket slot that is a member for SOME lane, the 128-byte alpha row comes through the scalar
+//              cache into SGPRs (wave-uniform address) and is added with v_pk_fma_f32(row, bit, acc): the exact
+//              addition for members, a no-op for the others.  No distance is evaluated a third time.
+// Both passes evaluate kdtree.h:180's DistanceSquared per lane in the reference's operation order, so the k-NN sets
+// are the reference's; only the order of the flux additions differs (as in lphoton).
+//
+// Radiance recurrence without a 30-bin carry.  The reference marches Lv = w_j + Tr_j * Lv (photonvolume.cpp:150-218)
+// with Tr_j = exp(-sigma_t * len_j) ASSIGNED per step, so the result is  Lv = sum_j w_j * exp(-sigma_t * R_j),
+// R_j = sum_{m > j} len_m.  A cheap geometric pre-loop gives every lane its total length; the march then adds each
+// step's contribution straight into X, Y, Z (or into the 30 bins for spectral output) -- 30 fewer live registers per
+// lane -- and makes every lookup's contribution INDEPENDENT of the others: a lane whose lookup does not fit the plan
+// (cold start, radius guess off twice, crowded bin, bucket overflow) appends {ray, point, R_j, step} to a list
+// instead of running the exact wave-cooperative lookup inline, and li_fixup_kernel adds those terms afterwards
+// (lphoton(), always exact).  The hot kernel therefore carries neither lphoton's registers nor its LDS: three waves
+// per SIMD.
 #define GRP_CH 512    // rays per chunk (ordered by scatter_u, then cut into groups of 64)
-#define GRP_CAP 512   // bucket capacity (photons)
-#define GRP_BINS 64   // histogram bins over [T/4, T), 4-bit counters (eight per LDS word)
+#define GRP_CAP 256   // bucket capacity (photons)
+#define GRP_NW (GRP_CAP / 32)     // 32-bit mask words per lane
+#define GRP_BINS 64   // histogram bins over [0, T), 4-bit counters (eight per LDS word) + one overflow word
 #define GRP_PITCH (GRP_CAP + 4)   // floats per bucket component (x | y | z | photon index), padded for the 4-wide passes
 #define GRP_WIDEN 1.7f   // a lane's search radius^2 may grow to this multiple of its guess where the bucket covers it
-#define GRP_MINI 8    // values of the k-th's bin a lane can sort
+#define GRP_MINI 8    // photons of the k-th's bin a lane can rank
 #define GRP_TRI_ROWS 8   // scenes with a distant light and at most this many triangles test shadow rays against precomputed rows
-#define GRP_WPE 2
+#define GRP_WPE 3     // waves per SIMD the register allocation must leave room for
+#define GRP_U_BYTES 4096   // shared scratch: stage paint list | histogram | chunk ordering | mini lists (never live together)
 
 struct GroupLds {
     float *pos;             // bucket, SoA: x[GRP_PITCH] | y | z | photon index bits
-    float *mini;            // [GRP_MINI][64] values of the k-th's bin, one column per lane
-    uint32_t *hist;         // [GRP_BINS / 8][64] packed 4-bit counters, one column per lane
-    float *ubuf;            // GRP_CH scatter offsets
+    uint32_t *hist;         // [GRP_BINS / 8 + 1][64] packed 4-bit counters, one column per lane (U region)
+    float *miniD;           // [GRP_MINI][64] values of the k-th's bin, one column per lane (U region)
+    float *ubuf;            // GRP_CH scatter offsets (U region)
     unsigned short *order;  // GRP_CH: chunk-local ray index by rank of scatter offset
     float *cst;             // 9 x 32 floats: sigA, sigS, le, albedo, light-0 intensity, 1/sigS, CIE X, Y, Z weights
-    unsigned short *clist;  // GRP_CAP bucket slots whose photon belongs to some lane's k-NN set
     float *trows;           // GRP_TRI_ROWS x 16 floats: per-triangle shadow-ray precomputation for a distant light
 };
 
@@ -139,37 +152,103 @@ __device__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, f
     return count;
 }
 
-__device__ __forceinline__ float dist2_ref(f4 P, V3 pt) {   // DistanceSquared(photon.p, p), kdtree.h:180
-    float dx = P.x - pt.x, dy = P.y - pt.y, dz = P.z - pt.z;
-    return dx * dx + dy * dy + dz * dz;
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
+// OR over the wave, every lane gets it (DPP + permlane swaps, no LDS)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_XOR1, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_QUAD_XOR2, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_HALF_MIRROR, 0xf, 0xf, true);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, DPP_ROW_ROR8, 0xf, 0xf, true);
+    { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = r[0] | r[1]; }
+    { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = r[0] | r[1]; }
+    return v;
 }
 
-template <bool STATS, int NREG>
+// Histogram bin of a DistanceSquared value: trunc(d2 * scale) clamped to GRP_BINS (= "not below T").  EXACT: lanes that
+// search the full radius must agree with the reference's `dist2 < maxDistSquared` (kdtree.h:180) to the last bit, so the
+// comparison itself decides in-range and the multiplication only places the value.
+template <bool EXACT>
+__device__ __forceinline__ uint32_t grp_bin(float d2, float scale, float Tl) {
+    uint32_t bin = (uint32_t)fminf(d2 * scale, (float)GRP_BINS);   // fminf also absorbs the sentinels' inf / NaN
+    if (EXACT) bin = d2 < Tl ? min(bin, (uint32_t)(GRP_BINS - 1)) : (uint32_t)GRP_BINS;
+    return bin;
+}
+
+// Pass 1: per-lane histogram of DistanceSquared over the bucket (padded to a multiple of four with far-away sentinels).
+template <bool EXACT>
+__device__ __forceinline__ void grp_pass1(const float *bX, const float *bY, const float *bZ, int Mb, nf4 px4, nf4 py4, nf4 pz4, float scale,
+                                          float Tl, uint32_t *histLane) {
+    nf4 nX = *reinterpret_cast<const nf4 *>(bX), nY = *reinterpret_cast<const nf4 *>(bY), nZ = *reinterpret_cast<const nf4 *>(bZ);
+    for (int c0 = 0; c0 < Mb; c0 += 4) {
+        // the next quartet's coordinates are requested before this one's arithmetic (the padded bucket makes the read past
+        // the end harmless); DistanceSquared(photon.p, p) (kdtree.h:180): same operations in the same order per element
+        const nf4 dx_ = nX - px4, dy_ = nY - py4, dz_ = nZ - pz4;
+        nX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); nY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); nZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
+        const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t bin = grp_bin<EXACT>(dd[u], scale, Tl);
+            atomicAdd(&histLane[(bin >> 3) * LANES], 1u << ((bin & 7u) << 2));   // ds_add_u32, no return
+        }
+    }
+}
+
+// Pass 2: per-lane bit masks over the bucket slots: lt = "bin < bstar", le = "bin <= bstar".
+template <bool EXACT>
+__device__ __forceinline__ void grp_pass2(const float *bX, const float *bY, const float *bZ, int Mb, nf4 px4, nf4 py4, nf4 pz4, float scale,
+                                          float Tl, uint32_t bstar, uint32_t (&lt)[GRP_NW], uint32_t (&le)[GRP_NW], float &dmax) {
+#pragma unroll
+    for (int wd = 0; wd < GRP_NW; ++wd) {
+        uint32_t mlt = 0u, mle = 0u;
+        if (wd * 32 < Mb) {   // wave-uniform
+            const int cend = min(Mb, wd * 32 + 32);
+            nf4 nX = *reinterpret_cast<const nf4 *>(bX + wd * 32), nY = *reinterpret_cast<const nf4 *>(bY + wd * 32), nZ = *reinterpret_cast<const nf4 *>(bZ + wd * 32);
+            for (int c0 = wd * 32; c0 < cend; c0 += 4) {
+                const nf4 dx_ = nX - px4, dy_ = nY - py4, dz_ = nZ - pz4;
+                nX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); nY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); nZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
+                const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t bin = grp_bin<EXACT>(dd[u], scale, Tl);
+                    const uint32_t isLt = bin < bstar ? 1u : 0u, isLe = bin <= bstar ? 1u : 0u;
+                    const int sh = (c0 + u) & 31;   // wave-uniform shift
+                    mlt |= isLt << sh;
+                    mle |= isLe << sh;
+                    if (EXACT) dmax = fmaxf(dmax, isLt ? dd[u] : 0.f);
+                }
+            }
+        }
+        lt[wd] = mlt;
+        le[wd] = mle;
+    }
+}
+
+__device__ __forceinline__ uint32_t nib_sum(uint32_t w) {   // sum of the eight 4-bit counters of a word
+    const uint32_t t = (w & 0x0f0f0f0fu) + ((w >> 4) & 0x0f0f0f0fu);
+    return (t * 0x01010101u) >> 24;
+}
+
+template <bool STATS, bool SPECTRAL>
 __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
-    MarchLds M;
-    // LDS plan (19.9 KB with candCap 256: eight waves per CU): prevRk | paint | bucket | mini | hist | cst | clist.
-    // The fallback lookup's candidate arrays alias the bucket (dead by then), the chunk-ordering scratch aliases mini + hist
-    // (used only between chunks; the groups' ray indices are taken into registers first).
-    M.G.cap = S.candCap;
-    M.lightNum = 0;
-    M.prevRk = reinterpret_cast<float *>(lds);
-    M.G.paint = reinterpret_cast<uint32_t *>(M.prevRk + PREV_N);
+    // LDS plan (11.7 KB: twelve waves per CU): prevRk | order | bucket | U | cst | trows
+    float *prevRk = reinterpret_cast<float *>(lds);
     GroupLds L;
-    L.pos = reinterpret_cast<float *>(M.G.paint + PAINT_CAP);
-    M.G.cd = L.pos;                                                  // candCap * 8 <= 4 * GRP_PITCH * 4 (checked on the host)
-    M.G.ci = reinterpret_cast<uint32_t *>(L.pos + M.G.cap);
-    L.mini = L.pos + 4 * GRP_PITCH;
-    L.hist = reinterpret_cast<uint32_t *>(L.mini + (GRP_MINI + 1) * LANES);
-    L.ubuf = L.mini;                                                 // GRP_CH floats
-    L.order = reinterpret_cast<unsigned short *>(L.ubuf + GRP_CH);   // GRP_CH shorts; both fit in mini + hist
-    L.cst = reinterpret_cast<float *>(L.hist + (GRP_BINS / 8) * LANES);
-    L.clist = reinterpret_cast<unsigned short *>(L.cst + 9 * 32);
-    L.trows = reinterpret_cast<float *>(lds + ((PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (GRP_CAP + 4) * 2 + 15) & ~15));
-    for (int i = lane; i < PREV_N; i += LANES) M.prevRk[i] = 0.f;
-    for (int i = lane; i < GRP_CAP + 4; i += LANES) L.clist[i] = 0;   // entries are read up to three past the list: keep them valid slots
+    L.order = reinterpret_cast<unsigned short *>(prevRk + PREV_N);
+    L.pos = reinterpret_cast<float *>(L.order + GRP_CH);
+    unsigned char *U = reinterpret_cast<unsigned char *>(L.pos + 4 * GRP_PITCH);
+    Gather G;
+    G.cap = 0; G.cd = 0; G.ci = 0;
+    G.paint = reinterpret_cast<uint32_t *>(U);
+    L.hist = reinterpret_cast<uint32_t *>(U);
+    L.miniD = reinterpret_cast<float *>(U);
+    L.ubuf = reinterpret_cast<float *>(U);
+    L.cst = reinterpret_cast<float *>(U + GRP_U_BYTES);
+    L.trows = L.cst + 9 * 32;
+    for (int i = lane; i < PREV_N; i += LANES) prevRk[i] = 0.f;
     const int q = lane & 7;
     const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
     const f4 sigT4 = sigA4 + sigS4;
@@ -199,10 +278,11 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     if (rowsOK) tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), L.trows, lane);
     const int k = S.nUsed;
     const float wIso = 1.f / (4.f * K_PI);
-    Rng rngNone;
-    rngNone.mt = 0; rngNone.mti = 0; rngNone.draws = 0;
+    const bool useLiiAny = (ySa1 != 0.0 || ySs1 != 0.0) && !blackS1;   // L_ii reaches the result at all (photonvolume.cpp:208-211)
     WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
+    const float *bX = L.pos, *bY = L.pos + GRP_PITCH, *bZ = L.pos + 2 * GRP_PITCH, *bI = L.pos + 3 * GRP_PITCH;
+    uint32_t *histLane = L.hist + lane;
     for (;;) {
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(A.chunkCounter, 1u);
@@ -224,37 +304,54 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
             L.order[rank] = (unsigned short)i;
         }
         __syncthreads();
-        unsigned short ordReg[GRP_CH / LANES];
-#pragma unroll
-        for (int g = 0; g < GRP_CH / LANES; ++g) ordReg[g] = (g * LANES + lane < nIn) ? L.order[g * LANES + lane] : (unsigned short)0;
-        __syncthreads();
 #pragma unroll 1
         for (int g0 = 0; g0 < nIn; g0 += LANES) {
             const bool have = g0 + lane < nIn;
-            unsigned short ordMine = ordReg[0];
-#pragma unroll
-            for (int g = 1; g < GRP_CH / LANES; ++g) ordMine = (g0 == g * LANES) ? ordReg[g] : ordMine;
-            const size_t ri = (size_t)r0 + (have ? (size_t)ordMine : 0u);
-            pvol_ray pr = A.rays[ri];
-            V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
+            const size_t ri = (size_t)r0 + (have ? (size_t)L.order[g0 + lane] : 0u);
+            const pvol_ray pr = A.rays[ri];
+            const V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
             RayD ray;
             ray.o = o; ray.d = d; ray.mint = pr.mint; ray.maxt = pr.maxt;
             float t0 = 0.f, t1 = 0.f;
             const bool hit = have && S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
             const int nS = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
             const float step = hit ? (t1 - t0) / nS : 0.f;
-            V3 pPrev = o + d * t0;
-            bool inPrev = hit && box_inside(S.extLo, S.extHi, xform_point(S.w2v, pPrev));
-            float tcur = t0 + pr.scatter_u * step;
-            const V3 w = -d;
-            float Lv[32];
-#pragma unroll
-            for (int b = 0; b < 32; ++b) Lv[b] = 0.f;
-            float lenLast = 0.f, lastRk = 0.f;
-            uint32_t uCount = 0;
-            bool bad = false;
+            const V3 pEntry = o + d * t0;
+            const bool inEntry = hit && box_inside(S.extLo, S.extHi, xform_point(S.w2v, pEntry));
+            const float tStart = t0 + pr.scatter_u * step;
             int maxN = nS;
             for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
+            // ---- pre-loop: this ray's total optical length sum_j len_j (the geometry of the march, nothing else)
+            float totalLen = 0.f;
+            {
+                float tc = tStart;
+                V3 pP = pEntry;
+                bool inP0 = inEntry;
+                for (int j = 0; j < maxN; ++j) {
+                    if (j < nS) {
+                        const V3 p = o + d * tc;
+                        tc += step;
+                        const bool inP = box_inside(S.extLo, S.extHi, xform_point(S.w2v, p));
+                        const V3 dseg = p - pP;
+                        float lenStep;
+                        if (inP0 && inP) { const V3 a = pP + dseg * 0.f, b = pP + dseg * 1.f; lenStep = len(a - b); }
+                        else lenStep = analytic_tau_length(S, pP, dseg, 0.f, 1.f);
+                        totalLen += lenStep;
+                        pP = p;
+                        inP0 = inP;
+                    }
+                }
+            }
+            V3 pPrev = pEntry;
+            bool inPrev = inEntry;
+            float tcur = tStart;
+            float Lv[SPECTRAL ? 32 : 1];
+#pragma unroll
+            for (int b = 0; b < (SPECTRAL ? 32 : 1); ++b) Lv[b] = 0.f;
+            float accX = 0.f, accY = 0.f, accZ = 0.f;
+            float lenLast = 0.f, lastRk = 0.f, cumLen = 0.f;
+            uint32_t uCount = 0;
+            bool bad = false;
             wc.rays += __popcll(__ballot(have));
             for (int j = 0; j < maxN; ++j) {
                 const bool act = j < nS;
@@ -264,14 +361,15 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 const bool inP = act && box_inside(S.extLo, S.extHi, pv);
                 float lenStep = 0.f;
                 if (act) {
-                    V3 dseg = p - pPrev;
+                    const V3 dseg = p - pPrev;
                     if (inPrev && inP) {
-                        V3 a = pPrev + dseg * 0.f, b = pPrev + dseg * 1.f;
+                        const V3 a = pPrev + dseg * 0.f, b = pPrev + dseg * 1.f;
                         lenStep = len(a - b);
                     } else {
                         lenStep = analytic_tau_length(S, pPrev, dseg, 0.f, 1.f);
                     }
                     if (!(lenStep * sigTmax < 6.8f)) bad = true;   // the roulette could fire: sequential kernel (photonvolume.cpp:156-161)
+                    cumLen += lenStep;
                 }
                 // ---- direct lighting geometry (photonvolume.cpp:178-203), light 0 (at most one light here)
                 float fallReg = 1.f, d2Reg = 1.f, exitLen = 0.f, ph = 0.f;
@@ -309,41 +407,46 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         V3 dv = xform_vector(S.w2v, vis.d);
                         V3 dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
                         exitLen = inside_exit_length(S, vis.o, vis.d, pv, dvInv, vis.maxt);
-                        ph = phase_hg(w, -wo, S.g);
+                        ph = phase_hg(-d, -wo, S.g);
                         ++uCount;
                     }
                 }
                 wc.steps += __popcll(__ballot(act));
                 if (STATS) wc.unocc += __popcll(__ballot(lit));
+                const float kRem = -1.442695041f * (totalLen - cumLen);   // exp(-sigma_t R_j) = exp2(sigma_t * kRem)
+                const float stepD = inP ? step : 0.f;
                 // ---- k-NN gather of the group
                 float acc[32];
 #pragma unroll
                 for (int b = 0; b < 32; ++b) acc[b] = 0.f;
                 float rk = 0.f;
                 int nFoundLane = k;
-                const bool need = inP && S.nPhotons > 0u;
-                bool done = !need;      // lanes whose L_ii is final
-                bool viaPlan = false;   // acc holds a raw flux sum of exactly k photons (scaled below)
-                const uint64_t needMask = __ballot(need);
-                if (needMask) {
-                    // The bucket plan, at most twice: lanes whose guessed radius turned out too small or too large get one more
-                    // shared attempt with a corrected radius (they come in clusters: ~11 lanes per affected step on C2) before
-                    // the per-lane exact lookup takes whatever is left.
-                    float Tretry = 0.f;
-                    for (int attempt = 0; attempt < 2; ++attempt) {
-                    const bool needP = need && !done && (attempt == 0 || Tretry > 0.f);
-                    if (!__ballot(needP)) break;
-                    // per-lane search radius^2: 1.3 x the larger of this ray's previous step and the previous group's
-                    // mean at this step; the full radius when neither exists.  The bucket covers the largest of them.
-                    float gbl = lastRk;
-                    if (j < PREV_N) gbl = fmaxf(gbl, M.prevRk[j]);
-                    float Tl = (gbl > 0.f && gbl * A.grpGuess < S.maxDistSq) ? gbl * A.grpGuess : S.maxDistSq;
-                    if (attempt == 1) { Tl = Tretry; gbl = 0.f; }   // second chance: the radius the first attempt asked for, no widening
-                    bool fullR = !(Tl < S.maxDistSq);
-                    float T = needP ? Tl : 0.f;
-                    T = wave_max(T);
-                    int Mb = -1;
-                    if (k >= 10 && k <= 64) {
+                const bool need = inP && S.nPhotons > 0u && useLiiAny;
+                bool done = !need;      // lanes whose L_ii is settled (served by the plan, or nothing to look up)
+                if (__ballot(need)) {
+                    // The bucket plan, up to three times.  Every attempt serves the lanes whose wanted radius^2 is within 3x of the
+                    // smallest one (a common bucket sized for an outlier would overflow for everybody); a lane that found too few
+                    // photons asks again with a radius scaled from the count it saw, a bucket overflow halves everybody's radius.
+                    // What is still open afterwards is handed to li_fixup_kernel.
+                    float guessBase = lastRk;
+                    if (j < PREV_N) guessBase = fmaxf(guessBase, prevRk[j]);
+                    {   // cold: what the other lanes found at their previous step, else the map-wide estimate
+                        const float nbr = wave_max(lastRk);
+                        if (!(guessBase > 0.f)) guessBase = nbr > 0.f ? nbr : S.rkEstimate;
+                    }
+                    float Twant = need ? ((guessBase * A.grpGuess < S.maxDistSq) ? guessBase * A.grpGuess : S.maxDistSq) : 0.f;
+                    for (int attempt = 0; attempt < 3; ++attempt) {
+                        bool needP = need && !done && Twant > 0.f;
+                        if (!__ballot(needP)) break;
+                        float Tl = Twant;
+                        if (attempt < 2) {
+                            const float Tmin = -wave_max(needP ? -Tl : -3.0e38f);
+                            needP = needP && !(Tl > 3.f * Tmin);   // the others wait for the next attempt with their Twant
+                        }
+                        const float gbl = Tl;
+                        bool fullR = !(Tl < S.maxDistSq);
+                        float T = needP ? Tl : 0.f;
+                        T = wave_max(T);
                         // centre and spread of the query points
                         const float big = 3.0e38f;
                         float lx = needP ? p.x : big, ly = needP ? p.y : big, lz = needP ? p.z : big;
@@ -355,247 +458,244 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         rho = wave_max(rho);
                         const float Rs = (sqrtf(T) + rho) * 1.0001f + 1e-6f;   // superset by the triangle inequality, with rounding slack
                         unsigned long long tst = 0, ts0 = STATS ? stamp() : 0ull;
-                        Mb = stage_bucket(S, M.G, L.pos, c, Rs, lane, tst);
-                        // the bucket covers more than this lane asked for when other lanes guessed larger: take it (up to
-                        // GRP_WIDEN x the guess) -- a wider search ball costs this lane nothing and spares it a failed guess
-                        if (needP && gbl > 0.f) {
+                        __syncthreads();   // the U region changes hands: mini lists -> paint list
+                        const int Mb = stage_bucket(S, G, L.pos, c, Rs, lane, tst);
+                        if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; }
+                        if (Mb < 0) {   // bucket overflow
+                            if (STATS) wc.diag1 += __popcll(__ballot(needP));
+                            if (needP) Twant = 0.4f * Tl;
+                            continue;
+                        }
+                        // the bucket covers more than this lane asked for when other lanes asked for more: take it (up to
+                        // GRP_WIDEN x) -- a wider search ball costs this lane nothing and spares it a failed guess
+                        if (needP) {
                             const float cover = (sqrtf(T) + rho) - len(p - c);
                             Tl = fminf(S.maxDistSq, fmaxf(Tl, fminf(cover * cover, gbl * GRP_WIDEN)));
                             fullR = !(Tl < S.maxDistSq);
                         }
-                        if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; }
-                    }
-                    if (STATS && Mb < 0) wc.diag1 += __popcll(needMask);   // bucket plan skipped (overflow, k out of range)
-                    if (Mb >= 0) {
                         const unsigned long long tp1 = STATS ? stamp() : 0ull;
-                        typedef float nf4 __attribute__((ext_vector_type(4)));
-                        const float *bX = L.pos, *bY = L.pos + GRP_PITCH, *bZ = L.pos + 2 * GRP_PITCH, *bI = L.pos + 3 * GRP_PITCH;
                         const nf4 px4 = {p.x, p.x, p.x, p.x}, py4 = {p.y, p.y, p.y, p.y}, pz4 = {p.z, p.z, p.z, p.z};
-                        // DistanceSquared(photon.p, p) (kdtree.h:180) of four bucket photons: same operations in the same order per
-                        // element, two elements per packed instruction
-#define GRP_D2X4(c0) ({ const nf4 dx_ = *reinterpret_cast<const nf4 *>(bX + (c0)) - px4, dy_ = *reinterpret_cast<const nf4 *>(bY + (c0)) - py4, \
-                                  dz_ = *reinterpret_cast<const nf4 *>(bZ + (c0)) - pz4; dx_ * dx_ + dy_ * dy_ + dz_ * dz_; })
-                        // ---- pass 1: per-lane histogram of DistanceSquared over [Tl/4, Tl).  The bucket is padded to a
-                        // multiple of four with far-away sentinels.
-                        const float Tlo = 0.25f * Tl;
-                        const float scale = (float)GRP_BINS / (Tl - Tlo);
+                        // ---- pass 1: histogram over [0, Tl)
+                        const float scale = needP ? (float)GRP_BINS / Tl : 0.f;   // lanes without a lookup put everything in the overflow word
+                        const bool exact = __ballot(needP && fullR) != 0ull;
 #pragma unroll
-                        for (int wd = 0; wd < GRP_BINS / 8; ++wd) L.hist[wd * LANES + lane] = 0u;
-                        int below = 0, cnt = 0;
-                        float dmax = 0.f;
-                        const float TlEff = needP ? Tl : -1.f;   // lanes without a lookup accept nothing
-                        const uint32_t histBase = (uint32_t)lane;
-                        nf4 nX = *reinterpret_cast<const nf4 *>(bX), nY = *reinterpret_cast<const nf4 *>(bY), nZ = *reinterpret_cast<const nf4 *>(bZ);
-                        for (int c0 = 0; c0 < Mb; c0 += 4) {
-                            // the next quartet's coordinates are requested before this one's arithmetic (the padded bucket makes the
-                            // read past the end harmless)
-                            const nf4 dx_ = nX - px4, dy_ = nY - py4, dz_ = nZ - pz4;
-                            nX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); nY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); nZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
-                            const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
+                        for (int wd = 0; wd <= GRP_BINS / 8; ++wd) histLane[wd * LANES] = 0u;
+                        if (exact) grp_pass1<true>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, histLane);
+                        else grp_pass1<false>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, histLane);
+                        // ---- prefix scan: word of the k-th, then its nibble
+                        int cum = 0, wsel = -1, cumWord = 0;
+                        uint32_t selBits = 0u;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {   // branch-free: predicates are 0/1 integers, the histogram add is +0 when not counted
-                                const float d2 = dd[u];
-                                const int inT = d2 < TlEff ? 1 : 0;
-                                const int low = d2 < Tlo ? 1 : 0;
-                                const int bin = min(GRP_BINS - 1, (int)((d2 - Tlo) * scale));
-                                cnt += inT;
-                                below += inT & low;
-                                dmax = fmaxf(dmax, inT ? d2 : 0.f);
-                                const int hb = (inT & (low ^ 1)) ? bin : 0;
-                                const uint32_t inc = (uint32_t)(inT & (low ^ 1)) << ((hb & 7) * 4);
-                                atomicAdd(&L.hist[(uint32_t)(hb >> 3) * LANES + histBase], inc);
-                            }
+                        for (int wd = 0; wd < GRP_BINS / 8; ++wd) {
+                            const uint32_t w = histLane[wd * LANES];
+                            const int t = (int)nib_sum(w);
+                            const bool here = wsel < 0 && cum + t >= k;
+                            wsel = here ? wd : wsel;
+                            selBits = here ? w : selBits;
+                            cumWord = here ? cum : cumWord;
+                            cum += t;
                         }
-                        bool ok = needP && cnt >= k && below < k;
-                        // the full radius holds fewer than k photons: all of them count, r^2 = the farthest (photonvolume.cpp:76-105)
-                        const bool shortSet = needP && fullR && cnt < k && cnt < 250;
-                        if (STATS && attempt == 0) wc.diag0 += __popcll(__ballot(needP && ((cnt < k && !shortSet) || (cnt >= k && below >= k))));   // radius guess too small / too large
-                        if (attempt == 0 && needP) {   // what a second attempt should search: 2.2 x (too few found) or 0.3 x (k-th below the histogram)
-                            if (cnt < k && !shortSet) Tretry = fminf(S.maxDistSq, 2.2f * Tl);
-                            else if (cnt >= k && below >= k) Tretry = 0.3f * Tl;
-                        }
-                        int bstar = -1, cumBelow = 0, binCount = 0;
-                        int cumAll = below;
+                        const int inRange = ((Mb + 3) & ~3) - (int)histLane[(GRP_BINS / 8) * LANES];
+                        int bstarI = -1, cumBelow = 0, binCount = 0;
                         {
+                            int c2 = cumWord;
 #pragma unroll
-                            for (int wd = 0; wd < GRP_BINS / 8; ++wd) {
-                                const uint32_t word = L.hist[wd * LANES + lane];
-#pragma unroll
-                                for (int s = 0; s < 8; ++s) {
-                                    const int cb = (int)((word >> (4 * s)) & 15u);
-                                    if (bstar < 0 && cumAll + cb >= k) { bstar = 8 * wd + s; cumBelow = cumAll; binCount = cb; }
-                                    cumAll += cb;
-                                }
+                            for (int s = 0; s < 8; ++s) {
+                                const int cb = (int)((selBits >> (4 * s)) & 15u);
+                                const bool here = bstarI < 0 && c2 + cb >= k;
+                                bstarI = here ? 8 * wsel + s : bstarI;
+                                cumBelow = here ? c2 : cumBelow;
+                                binCount = here ? cb : binCount;
+                                c2 += cb;
                             }
                         }
-                        // a 4-bit counter that wrapped (> 15 values in one bin) makes the counters' total fall short of cnt: not trusted
-                        ok = ok && bstar >= 0 && binCount <= GRP_MINI && cumAll == cnt;
-                        // ---- pass 2: (a) the values of bin bstar go to the lane's mini list; (b) every bucket photon that can
-                        // belong to SOME lane's k-NN set (it lies in a bin <= that lane's bstar) goes to the compact list, in bucket order
-                        int nb = 0, nC = 0;
+                        // a 4-bit counter that wrapped makes the counters' total fall short of the in-range count: not trusted
+                        const bool sane = needP && cum == inRange;
+                        bool ok = sane && wsel >= 0 && bstarI >= 0 && binCount <= GRP_MINI;
+                        // the full radius holds fewer than k photons: all of them count, r^2 = the farthest (photonvolume.cpp:76-105)
+                        const bool shortSet = sane && fullR && inRange < k;
+                        const bool tooFew = needP && !fullR && cum < k;
+                        if (STATS && attempt == 0) wc.diag0 += __popcll(__ballot(needP && !ok && !shortSet));
+                        if (needP) {   // what to ask for next time (0 = nothing: crowded bin or wrapped counter, the exact lookup takes it)
+                            Twant = 0.f;
+                            if (tooFew) {   // the count seen inside Tl gives the local density: k photons need ~ (k / count)^(2/3) x Tl
+                                const float grow = cum > 0 ? 1.35f * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf((float)k / (float)cum)) : 1.0e9f;
+                                Twant = fminf(S.maxDistSq, Tl * fmaxf(1.5f, grow));
+                            }
+                        }
                         const bool planLane = ok || shortSet;
                         if (__ballot(planLane)) {
-                            const float TlPlan = planLane ? Tl : -1.f;
-                            const int bEq = ok ? bstar : -1000;                    // bin whose values are kept (none for short sets)
-                            const int bLe = shortSet ? 1000 : (ok ? bstar : -1000);   // last bin that can hold a member
-                            nf4 mX = *reinterpret_cast<const nf4 *>(bX), mY = *reinterpret_cast<const nf4 *>(bY), mZ = *reinterpret_cast<const nf4 *>(bZ);
-                            for (int c0 = 0; c0 < Mb; c0 += 4) {
-                                const nf4 dx_ = mX - px4, dy_ = mY - py4, dz_ = mZ - pz4;
-                                mX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); mY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); mZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
-                                const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
+                            // ---- pass 2: member bits
+                            uint32_t mem[GRP_NW], le[GRP_NW];
+                            float dmax = 0.f;
+                            const uint32_t bstar = shortSet ? (uint32_t)GRP_BINS : (ok ? (uint32_t)bstarI : 0u);
+                            __syncthreads();
+                            if (exact) grp_pass2<true>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, bstar, mem, le, dmax);
+                            else grp_pass2<false>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, bstar, mem, le, dmax);
+                            // ---- the photons of bin b*: their exact values into the lane's mini list (slot order)
+                            int nb = 0;
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {   // branch-free; bins below the histogram range count as -1
-                                    const float d2 = dd[u];
-                                    const int inT = d2 < TlPlan ? 1 : 0;
-                                    const int binH = min(GRP_BINS - 1, (int)((d2 - Tlo) * scale));
-                                    const int bin = d2 < Tlo ? -1 : binH;
-                                    const int inBin = inT & (bin == bEq ? 1 : 0);
-                                    L.mini[nb * LANES + lane] = d2;   // kept only if inBin: the slot is overwritten otherwise
-                                    nb += inBin;
-                                    const int possible = inT & (bin <= bLe ? 1 : 0);
-                                    L.clist[nC] = (unsigned short)(c0 + u);   // every lane stores the same value; kept only if some lane may needP it
-                                    nC += __ballot(possible != 0) != 0ull ? 1 : 0;
+                            for (int wd = 0; wd < GRP_NW; ++wd) {
+                                if (wd * 32 >= Mb) continue;   // wave-uniform
+                                uint32_t ib = ok ? (le[wd] & ~mem[wd]) : 0u;
+                                while (__ballot(ib != 0u)) {
+                                    const bool v = ib != 0u;
+                                    const int slot = wd * 32 + (v ? __builtin_ctz(ib) : 0);
+                                    const float dx = bX[slot] - p.x, dy = bY[slot] - p.y, dz = bZ[slot] - p.z;
+                                    const float d2 = dx * dx + dy * dy + dz * dz;
+                                    if (v && nb < GRP_MINI) L.miniD[nb * LANES + lane] = d2;
+                                    nb += v ? 1 : 0;
+                                    ib &= ib - 1u;
                                 }
                             }
-                        }
-                        // sort the mini list (<= GRP_MINI values; absent slots are +inf): odd-even transposition network
-                        float sv[GRP_MINI];
+                            __syncthreads();
+                            // sort (<= GRP_MINI values; absent slots are +inf): odd-even transposition network
+                            float sv[GRP_MINI];
 #pragma unroll
-                        for (int t = 0; t < GRP_MINI; ++t) sv[t] = t < nb ? L.mini[t * LANES + lane] : INFINITY;
+                            for (int t = 0; t < GRP_MINI; ++t) sv[t] = t < nb ? L.miniD[t * LANES + lane] : INFINITY;
 #pragma unroll
-                        for (int rnd = 0; rnd < GRP_MINI; ++rnd) {
+                            for (int rnd = 0; rnd < GRP_MINI; ++rnd) {
 #pragma unroll
-                            for (int t = rnd & 1; t + 1 < GRP_MINI; t += 2) {
-                                const float lo = fminf(sv[t], sv[t + 1]), hi = fmaxf(sv[t], sv[t + 1]);
-                                sv[t] = lo; sv[t + 1] = hi;
+                                for (int t = rnd & 1; t + 1 < GRP_MINI; t += 2) {
+                                    const float lo = fminf(sv[t], sv[t + 1]), hi = fmaxf(sv[t], sv[t + 1]);
+                                    sv[t] = lo; sv[t + 1] = hi;
+                                }
                             }
-                        }
-                        const int m = k - cumBelow;   // 1-based rank of the k-th inside its bin
-                        float rkC = sv[0];   // this attempt's k-th distance^2 (rk itself belongs to the lanes already served)
-                        int nLessIn = 0;
+                            const int m = k - cumBelow;   // 1-based rank of the k-th inside its bin
+                            float rkC = sv[0];
 #pragma unroll
-                        for (int t = 1; t < GRP_MINI; ++t) rkC = (m == t + 1) ? sv[t] : rkC;
+                            for (int t = 1; t < GRP_MINI; ++t) rkC = (m == t + 1) ? sv[t] : rkC;
+                            int nLessIn = 0;
 #pragma unroll
-                        for (int t = 0; t < GRP_MINI; ++t) nLessIn += (sv[t] < rkC) ? 1 : 0;
-                        int quota0 = k - cumBelow - nLessIn;   // ties at rkC are taken in bucket order
-                        ok = ok && rkC < Tl;
-                        if (shortSet) { ok = true; rkC = dmax; quota0 = 256; }
-                        const unsigned long long tp3 = STATS ? stamp() : 0ull;
-                        if (STATS) wc.cySelect += tp3 - tp1;
-                        // ---- pass 3: flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
-                        // (constant address space: the map is read-only while this kernel runs) and cost no vector-memory
-                        // bandwidth.  Two list entries per iteration; acc = fma(row, 0 or 1, acc) is the exact addition for
-                        // members and a no-op for the others, without a branch.
-                        nC = __builtin_amdgcn_readfirstlane(nC);
-                        if (lane == 0) L.clist[nC] = (unsigned short)Mb;   // odd count: pair the last entry with a sentinel slot (never a member)
-                        __syncthreads();
-                        if (nC && __ballot(ok)) {
+                            for (int t = 0; t < GRP_MINI; ++t) nLessIn += (sv[t] < rkC) ? 1 : 0;
+                            int quota = m - nLessIn;   // ties at rkC are taken in bucket order
+                            ok = ok && nb == binCount && rkC < INFINITY;
+                            // member bits of bin b*: d2 < r_k, or d2 == r_k while the tie quota lasts
+                            {
+                                int t2 = 0;
+#pragma unroll
+                                for (int wd = 0; wd < GRP_NW; ++wd) {
+                                    if (wd * 32 >= Mb) continue;
+                                    uint32_t ib = ok ? (le[wd] & ~mem[wd]) : 0u;
+                                    while (__ballot(ib != 0u)) {
+                                        const bool v = ib != 0u;
+                                        const uint32_t bit = v ? (ib & (0u - ib)) : 0u;
+                                        const float dv = L.miniD[min(t2, GRP_MINI - 1) * LANES + lane];
+                                        const bool tie = v && dv == rkC && quota > 0;
+                                        if (tie) --quota;
+                                        if (v && (dv < rkC || tie)) mem[wd] |= bit;
+                                        t2 += v ? 1 : 0;
+                                        ib &= ib - 1u;
+                                    }
+                                }
+                            }
+                            if (shortSet) { ok = true; rkC = dmax; }
+                            const unsigned long long tp3 = STATS ? stamp() : 0ull;
+                            if (STATS) wc.cySelect += tp3 - tp1;
+                            // ---- flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
+                            // (constant address space: the map is read-only while this kernel runs) and cost no vector-memory
+                            // bandwidth.  Two slots per iteration; acc = fma(row, 0 or 1, acc) is the exact addition for
+                            // members and a no-op for the others, without a branch.
                             typedef const __attribute__((address_space(4))) nf4 cf4;
-                            int quota = quota0;
-                            // the LDS side of the next pair (list entries, coordinates, photon indices) is read one iteration ahead
-                            int nca = (int)L.clist[0], ncb = (int)L.clist[1];
-                            float nax = bX[nca], nay = bY[nca], naz = bZ[nca], nbx = bX[ncb], nby = bY[ncb], nbz = bZ[ncb];
-                            float nia = bI[nca], nib = bI[ncb];
-                            for (int i = 0; i < nC; i += 2) {
-                                const float ax = nax, ay = nay, az = naz, bx = nbx, by = nby, bz = nbz;
-                                cf4 *ra = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nia)) * 8);
-                                cf4 *rb = (cf4 *)(S.alpha4 + (size_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(nib)) * 8);
-                                nca = (int)L.clist[i + 2]; ncb = (int)L.clist[i + 3];   // past the end: stale but in-range slots, never used
-                                nax = bX[nca]; nay = bY[nca]; naz = bZ[nca]; nbx = bX[ncb]; nby = bY[ncb]; nbz = bZ[ncb];
-                                nia = bI[nca]; nib = bI[ncb];
-                                nf4 rowA[8], rowB[8];
 #pragma unroll
-                                for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
-                                const float dA = dist2_ref(make_float4(ax, ay, az, 0.f), p), dB = dist2_ref(make_float4(bx, by, bz, 0.f), p);
-                                bool mA = ok && dA < rkC;
-                                if (ok && dA == rkC && quota > 0) { mA = true; --quota; }
-                                bool mB = ok && dB < rkC;
-                                if (ok && dB == rkC && quota > 0) { mB = true; --quota; }
-                                const float fA = mA ? 1.f : 0.f, fB = mB ? 1.f : 0.f;
+                            for (int wd = 0; wd < GRP_NW; ++wd) {
+                                if (wd * 32 >= Mb) continue;
+                                const uint32_t mine = ok ? mem[wd] : 0u;
+                                uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or(mine));
+                                if (!any) continue;
+                                const int idxW = (int)__float_as_uint(bI[wd * 32 + (lane & 31)]);   // this word's photon indices, one per lane
+                                while (any) {
+                                    const int b0 = __builtin_ctz(any);
+                                    any &= any - 1u;
+                                    const bool two = any != 0u;
+                                    const int b1 = two ? __builtin_ctz(any) : b0;
+                                    any &= any - 1u;   // 0 & anything stays 0
+                                    cf4 *ra = (cf4 *)(S.alpha4 + (size_t)(uint32_t)__builtin_amdgcn_readlane(idxW, b0) * 8);
+                                    cf4 *rb = (cf4 *)(S.alpha4 + (size_t)(uint32_t)__builtin_amdgcn_readlane(idxW, b1) * 8);
+                                    nf4 rowA[8], rowB[8];
 #pragma unroll
-                                for (int qq = 0; qq < 8; ++qq) {
-                                    acc[4 * qq] = __builtin_fmaf(rowA[qq].x, fA, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowA[qq].y, fA, acc[4 * qq + 1]);
-                                    acc[4 * qq + 2] = __builtin_fmaf(rowA[qq].z, fA, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowA[qq].w, fA, acc[4 * qq + 3]);
-                                }
+                                    for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
+                                    const float fA = (float)((mine >> b0) & 1u), fB = two ? (float)((mine >> b1) & 1u) : 0.f;
 #pragma unroll
-                                for (int qq = 0; qq < 8; ++qq) {
-                                    acc[4 * qq] = __builtin_fmaf(rowB[qq].x, fB, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowB[qq].y, fB, acc[4 * qq + 1]);
-                                    acc[4 * qq + 2] = __builtin_fmaf(rowB[qq].z, fB, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowB[qq].w, fB, acc[4 * qq + 3]);
+                                    for (int qq = 0; qq < 8; ++qq) {
+                                        acc[4 * qq] = __builtin_fmaf(rowA[qq].x, fA, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowA[qq].y, fA, acc[4 * qq + 1]);
+                                        acc[4 * qq + 2] = __builtin_fmaf(rowA[qq].z, fA, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowA[qq].w, fA, acc[4 * qq + 3]);
+                                    }
+#pragma unroll
+                                    for (int qq = 0; qq < 8; ++qq) {
+                                        acc[4 * qq] = __builtin_fmaf(rowB[qq].x, fB, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowB[qq].y, fB, acc[4 * qq + 1]);
+                                        acc[4 * qq + 2] = __builtin_fmaf(rowB[qq].z, fB, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowB[qq].w, fB, acc[4 * qq + 3]);
+                                    }
                                 }
                             }
+                            if (ok) { done = true; rk = rkC; if (shortSet) nFoundLane = inRange; }
+                            if (STATS) { wc.kept += (unsigned long long)k * __popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
                         }
-#undef GRP_D2X4
-                        if (ok) { done = true; viaPlan = true; rk = rkC; if (shortSet) nFoundLane = cnt; }
-                        if (STATS) { wc.kept += (unsigned long long)k * __popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
-                    }
                     }   // attempt
-                    // ---- lanes the plan did not serve: the wave-cooperative exact lookup, one lane at a time
-                    uint64_t todo = __ballot(need && !done);
-                    WaveCounters wsave = wc;
-                    const unsigned long long tfb = STATS ? stamp() : 0ull;
-                    const int nfb = __popcll(todo);
-                    while (todo) {
-                        const int l = __ffsll((unsigned long long)todo) - 1;
-                        todo &= todo - 1;
-                        const V3 pl = v3(lane_f(p.x, l), lane_f(p.y, l), lane_f(p.z, l));
-                        const V3 wl = v3(lane_f(w.x, l), lane_f(w.y, l), lane_f(w.z, l));
-                        const float gl = lane_f(lastRk, l);
-                        float guess = gl;
-                        if (j < PREV_N) guess = fmaxf(guess, M.prevRk[j]);
-                        float rkl;
-                        const f4 Lf = lphoton<STATS, NREG>(S, M.G, wl, pl, sigS4, lane, wc, guess, &rkl);   // inside the extent: sigma_s * 1
-                        const float lf[4] = {Lf.x, Lf.y, Lf.z, Lf.w};
-#pragma unroll
-                        for (int qq = 0; qq < 8; ++qq) {
-#pragma unroll
-                            for (int cc = 0; cc < 4; ++cc) {
-                                const float v = lane_f(lf[cc], qq);
-                                if (lane == l) acc[4 * qq + cc] = v;
+                    // ---- lanes the plan did not serve: their term is added by li_fixup_kernel (exact lookup), nothing else waits for it
+                    const uint64_t todo = __ballot(need && !done);
+                    if (todo) {
+                        const int nfb = __popcll(todo);
+                        uint32_t base = 0;
+                        if (lane == 0) base = atomicAdd(A.deferCount, (uint32_t)nfb);
+                        base = (uint32_t)lane_i((int)base, 0);
+                        if (need && !done) {
+                            const uint32_t at = base + lanes_below(todo, lane);
+                            if (at < A.deferCap) {
+                                DeferRec r;
+                                r.ray = (uint32_t)ri; r.px = p.x; r.py = p.y; r.pz = p.z; r.kRem = kRem; r.stepD = stepD;
+                                r.guess = guessBase > 0.f ? guessBase : 0.f; r.pad = 0u;
+                                A.defer[at] = r;
+                            } else {
+                                atomicOr(A.needSeq, 1u);   // list full: the batch is redone by the sequential kernel, never dropped
                             }
                         }
-                        if (lane == l) rk = rkl;
+                        if (STATS) wc.retries += nfb;
                     }
-                    if (STATS) { wc = wsave; wc.retries += nfb; wc.diag2 += stamp() - tfb; }   // the exact lookups are accounted as retries + their cycles, not in the phase counters
-                    const float rkGuess = (need && nFoundLane >= k) ? rk : 0.f;   // as lphoton's rkOut: a k-th distance exists only for full sets
+                    // a k-th distance exists only for full sets; a short set says "search the full radius here"
+                    const float rkGuess = (need && done) ? (nFoundLane >= k ? rk : S.maxDistSq) : 0.f;
                     {   // mean k-th distance^2 of the group at this step -> guess of the next group
                         float sr = rkGuess, sn = rkGuess > 0.f ? 1.f : 0.f;
                         for (int off = 32; off > 0; off >>= 1) { sr += __shfl_xor(sr, off); sn += __shfl_xor(sn, off); }
-                        if (j < PREV_N && lane == 0) M.prevRk[j] = sn > 0.f ? sr / sn : 0.f;
+                        if (j < PREV_N && lane == 0 && sn > 0.f) prevRk[j] = sr / sn;
                     }
                     if (need) lastRk = rkGuess;
                 }
-                // ---- the recurrence of photonvolume.cpp:150-218, 30 bins per lane.  Per-lane scalars first:
-                //   L_ii = Sum(alpha) * phase / (4/3 pi r^3 sigma_s)     (photonvolume.cpp:99-105; planned lanes hold the raw sum)
-                //   L_d  = I * [falloff / d^2] * exp(-sigma_t * exit) * phase * nLights          (:178-203)
+                // ---- this step's term of  Lv = sum_j w_j exp(-sigma_t R_j)  (photonvolume.cpp:150-218), 30 bins per lane:
+                //   w_j  = sigma_a Le step + sigma_s step (L_d + albedo L_ii)
+                //   L_ii = Sum(alpha) * phase / (4/3 pi r^3 sigma_s)                        (:99-105; acc holds the raw sum)
+                //   L_d  = I * [falloff / d^2] * exp(-sigma_t * exit) * phase * nLights      (:178-203)
                 float liiScale = 0.f;   // raw sum -> L_ii * sigma_s
-                if (viaPlan) {
+                if (need && done) {
                     const float dV = rk * sqrtf(rk);
-                    if (dV != 0.f && !blackS1 && nFoundLane >= 10) liiScale = wIso * __builtin_amdgcn_rcpf(float(4.0 / 3.0 * (double)K_PI * (double)dV));
+                    if (dV != 0.f && nFoundLane >= 10) liiScale = wIso * __builtin_amdgcn_rcpf(float(4.0 / 3.0 * (double)K_PI * (double)dV));
                 }
-                const float dens = inP ? 1.f : 0.f;
                 const bool useLii = inP && (ySa1 != 0.0 || ySs1 != 0.0);
                 float ldScale = 0.f;
                 if (lit) ldScale = (distant ? 1.f : fallReg * __builtin_amdgcn_rcpf(d2Reg)) * ph * float(nLights);
-                const float kLen = -1.442695041f * lenStep, kExit = -1.442695041f * exitLen;   // exp(-x) = exp2(-x log2 e)
-                const float stepD = step * dens;
+                const float kExit = -1.442695041f * exitLen;   // exp(-x) = exp2(-x log2 e)
                 if (act) {
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         __builtin_amdgcn_sched_barrier(0);   // keep the constants of one bin quartet live at a time
                         const f4 a4 = cA[qq], s4 = cS[qq], le4 = cLe[qq], al4 = cAl[qq], i4 = cI[qq], r4 = cRs[qq];
+                        const f4 x4 = cX[qq], y4 = cY[qq], z4 = cZ[qq];
                         const float av[4] = {a4.x, a4.y, a4.z, a4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, lev[4] = {le4.x, le4.y, le4.z, le4.w};
                         const float alv[4] = {al4.x, al4.y, al4.z, al4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                        const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) {
                             const int b = 4 * qq + cc;
                             if (b >= 30) continue;
                             const float sT = av[cc] + sv[cc];
-                            const float Trb = __builtin_amdgcn_exp2f(sT * kLen);
+                            const float Pj = __builtin_amdgcn_exp2f(sT * kRem);
                             const float Ld = (iv[cc] * ldScale) * __builtin_amdgcn_exp2f(sT * kExit);
-                            float Lii = acc[b];
-                            if (viaPlan) Lii = acc[b] * liiScale * rv[cc];
+                            const float Lii = acc[b] * liiScale * rv[cc];
                             const float Li = useLii ? Ld + alv[cc] * Lii : Ld;
-                            Lv[b] = (av[cc] * lev[cc] * stepD) + (sv[cc] * Li * stepD) + (Trb * Lv[b]);
+                            const float w = (av[cc] * lev[cc] * stepD) + (sv[cc] * Li * stepD);
+                            const float t = Pj * w;
+                            if (SPECTRAL) Lv[b] += t;
+                            else { accX += xv[cc] * t; accY += yv[cc] * t; accZ += zv[cc] * t; }
                         }
                     }
                     pPrev = p;
@@ -610,7 +710,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 } else {
                     const uint32_t draws = hit ? 4u + 7u * (uint32_t)nS + uCount : 0u;
                     const float kLast = -1.442695041f * lenLast;
-                    if (A.outputKind == PVOL_OUT_SPECTRAL) {
+                    if (SPECTRAL) {
                         float *op = A.out + ri * 60;
 #pragma unroll
                         for (int b = 0; b < 30; ++b) {
@@ -618,26 +718,20 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             op[30 + b] = hit ? __builtin_amdgcn_exp2f((L.cst[b] + L.cst[32 + b]) * kLast) : 1.f;
                         }
                     } else {
-                        float x = 0.f, y = 0.f, z = 0.f, ty = 0.f;
+                        float ty = 0.f;
 #pragma unroll
                         for (int qq = 0; qq < 8; ++qq) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            const f4 a4 = cA[qq], s4 = cS[qq], x4 = cX[qq], y4 = cY[qq], z4 = cZ[qq];
-                            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
-                            const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
+                            const f4 a4 = cA[qq], s4 = cS[qq], y4 = cY[qq];
+                            const float av[4] = {a4.x, a4.y, a4.z, a4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
                             for (int cc = 0; cc < 4; ++cc) {
-                                const int b = 4 * qq + cc;
-                                if (b >= 30) continue;
-                                x += xv[cc] * Lv[b];
-                                y += yv[cc] * Lv[b];
-                                z += zv[cc] * Lv[b];
+                                if (4 * qq + cc >= 30) continue;
                                 const float trb = hit ? __builtin_amdgcn_exp2f((av[cc] + sv[cc]) * kLast) : 1.f;
                                 ty += yv[cc] * trb;
                             }
                         }
                         const float scale = float(700 - 400) / float(106.856895f * 30);
-                        *reinterpret_cast<f4 *>(A.out + ri * 4) = make_float4(x * scale, y * scale, z * scale, ty * 300.f / (106.856895f * 30));
+                        *reinterpret_cast<f4 *>(A.out + ri * 4) = make_float4(accX * scale, accY * scale, accZ * scale, ty * 300.f / (106.856895f * 30));
                     }
                     if (A.draws) A.draws[ri] = draws;
                 }
@@ -663,15 +757,77 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
 
-extern "C" size_t pvol_group_lds_bytes(int candCap) {
-    (void)candCap;   // the fallback candidate arrays alias the bucket
-    return (size_t)PREV_N * 4 + PAINT_CAP * 4 + (GRP_CAP + 4) * 16 + (GRP_MINI + 1) * LANES * 4 + (GRP_BINS / 8) * LANES * 4 + 9 * 32 * 4 + (((GRP_CAP + 4) * 2 + 15) & ~15) + GRP_TRI_ROWS * 64;
+// The lookups li_group_kernel handed over: one wave per entry runs the exact wave-cooperative lphoton() and adds the
+// entry's term  exp(-sigma_t R_j) sigma_s step albedo L_ii  to the ray's output (atomic: a ray can have several entries).
+template <bool STATS, bool SPECTRAL>
+__global__ __launch_bounds__(LANES, PVOL_WPE) void li_fixup_kernel(LiArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    if (*A.needSeq != 0u) return;   // the whole batch is redone sequentially
+    const uint32_t n = min(*A.deferCount, A.deferCap);
+    Gather G;
+    G.cap = S.candCap;
+    G.cd = reinterpret_cast<float *>(lds);
+    G.ci = reinterpret_cast<uint32_t *>(lds + (size_t)G.cap * 4);
+    G.paint = reinterpret_cast<uint32_t *>(lds + (size_t)G.cap * 8);
+    const int q = lane & 7;
+    const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
+    const f4 sigT4 = sigA4 + sigS4;
+    const f4 albedo4 = clean4(fdiv4(sigS4, sigT4), q);
+    const f4 X4 = ld4(S.cieX, q), Y4 = ld4(S.cieY, q), Z4 = ld4(S.cieZ, q);
+    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long tk0 = STATS ? stamp() : 0ull;
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const DeferRec r = A.defer[e];
+        float rk;
+        const f4 Lii = lphoton<STATS, 4>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4, lane, wc, r.guess, &rk);   // g == 0: the direction is not read
+        const f4 kk = sigT4 * r.kRem;
+        f4 c = make_float4(__builtin_amdgcn_exp2f(kk.x), __builtin_amdgcn_exp2f(kk.y), __builtin_amdgcn_exp2f(kk.z), __builtin_amdgcn_exp2f(kk.w));
+        c = clean4(c * (sigS4 * (albedo4 * Lii) * r.stepD), q);
+        if (SPECTRAL) {
+            if (lane < 8) {
+                float *op = A.out + (size_t)r.ray * 60 + 4 * q;
+                const float cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) if (4 * q + cc < 30 && cv[cc] != 0.f) atomicAdd(op + cc, cv[cc]);
+            }
+        } else {
+            const float scale = float(700 - 400) / float(106.856895f * 30);
+            const float x = group8_sum(X4.x * c.x + X4.y * c.y + X4.z * c.z + X4.w * c.w) * scale;
+            const float y = group8_sum(Y4.x * c.x + Y4.y * c.y + Y4.z * c.z + Y4.w * c.w) * scale;
+            const float z = group8_sum(Z4.x * c.x + Z4.y * c.y + Z4.z * c.z + Z4.w * c.w) * scale;
+            if (lane == 0) {
+                float *op = A.out + (size_t)r.ray * 4;
+                atomicAdd(op, x); atomicAdd(op + 1, y); atomicAdd(op + 2, z);
+            }
+        }
+    }
+    wc.rays = 0; wc.steps = 0;   // the march steps were counted by li_group_kernel
+    flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
 
-extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream) {
+extern "C" size_t pvol_group_lds_bytes(int candCap) {
+    (void)candCap;
+    return (size_t)PREV_N * 4 + GRP_CH * 2 + (size_t)GRP_PITCH * 16 + GRP_U_BYTES + 9 * 32 * 4 + GRP_TRI_ROWS * 64;
+}
+
+extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
+                                           hipStream_t stream) {
     hipLaunchKernelGGL(stream_begin_kernel, dim3((args->nStreams + 255) / 256), dim3(256), 0, stream, args->streams, args->nStreams);
     dim3 grid(nWaves), block(LANES);
-    if (stats) hipLaunchKernelGGL((li_group_kernel<true, 4>), grid, block, ldsBytes, stream, *args);
-    else hipLaunchKernelGGL((li_group_kernel<false, 4>), grid, block, ldsBytes, stream, *args);
+    const bool spectral = args->outputKind == PVOL_OUT_SPECTRAL;
+    const size_t fixLds = (size_t)candCap * 8 + PAINT_CAP * 4;
+    if (stats) {
+        if (spectral) { hipLaunchKernelGGL((li_group_kernel<true, true>), grid, block, ldsBytes, stream, *args);
+                        hipLaunchKernelGGL((li_fixup_kernel<true, true>), dim3(nFixWaves), block, fixLds, stream, *args); }
+        else { hipLaunchKernelGGL((li_group_kernel<true, false>), grid, block, ldsBytes, stream, *args);
+               hipLaunchKernelGGL((li_fixup_kernel<true, false>), dim3(nFixWaves), block, fixLds, stream, *args); }
+    } else {
+        if (spectral) { hipLaunchKernelGGL((li_group_kernel<false, true>), grid, block, ldsBytes, stream, *args);
+                        hipLaunchKernelGGL((li_fixup_kernel<false, true>), dim3(nFixWaves), block, fixLds, stream, *args); }
+        else { hipLaunchKernelGGL((li_group_kernel<false, false>), grid, block, ldsBytes, stream, *args);
+               hipLaunchKernelGGL((li_fixup_kernel<false, false>), dim3(nFixWaves), block, fixLds, stream, *args); }
+    }
     return hipGetLastError();
 }

@@ -28,6 +28,9 @@ struct LiArgs {
     uint32_t *state;
     float grpGuess;
     int liteResolve;
+    DeferRec *defer;            // li_group_kernel: lookups handed to li_fixup_kernel
+    uint32_t *deferCount;
+    uint32_t deferCap;
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
@@ -43,7 +46,8 @@ extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, in
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
                                            uint32_t nWaves, hipStream_t stream, bool resolve);
 extern "C" size_t pvol_group_lds_bytes(int candCap);
-extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
+extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
+                                           hipStream_t stream);
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused);
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
@@ -62,7 +66,9 @@ struct pvol_ctx {
     float4 *dPos4, *dAlpha4, *dWi4;
     uint32_t *dCellStart;
     DevCounters *dCounters;
-    uint32_t *dWords;   // [0] chunk counter of li_par_kernel, [1] needSeq flag
+    uint32_t *dWords;   // [0] chunk counter of the ray-parallel kernels, [1] needSeq flag, [2] length of the deferred-lookup list
+    DeferRec *dDefer = 0;   // li_group_kernel's deferred lookups (grown on demand)
+    size_t deferCap = 0;
     int nCU;
     float maxDensity = 1.f;   // largest density factor of the medium (1 for analytic volumes, max of the grid values)
     bool noLite = false;      // PVOL_NO_LITE=1: keep the geometry inside the sequential resolve pass (testing)

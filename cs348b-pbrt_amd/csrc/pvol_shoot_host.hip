@@ -14,10 +14,10 @@ struct ShootArgs {
     const DevScene *scene;
     const DevShootScene *shoot;
     uint32_t nTasks;
-    uint32_t *mt;
+    const uint32_t *stateIn;
+    uint32_t *stateOut;
     uint32_t *halton;
-    uint32_t *totalPaths;
-    uint32_t *flags;
+    const uint32_t *flags;
     float *localPhotons;
     uint32_t *localCounts;
     uint32_t cap;
@@ -35,13 +35,14 @@ struct MergeArgs {
     float *p, *wi, *alpha;
 };
 extern "C" hipError_t pvol_launch_shoot(const ShootArgs *a, hipStream_t stream);
+extern "C" size_t pvol_shoot_state_words(void);
 extern "C" hipError_t pvol_launch_merge(const MergeArgs *m, hipStream_t stream);
 
 static bool ok(hipError_t e) { return e == hipSuccess; }
 
 namespace {
 struct Buffers {
-    uint32_t *mt = 0, *halton = 0, *totalPaths = 0, *flags = 0, *localCounts = 0;
+    uint32_t *stateA = 0, *stateB = 0, *halton = 0, *flags = 0, *localCounts = 0;
     float *localPhotons = 0;
     unsigned long long *stats = 0;
     uint32_t *segTask = 0, *segCount = 0, *segOff = 0;
@@ -49,7 +50,7 @@ struct Buffers {
     float *p = 0, *wi = 0, *alpha = 0;   // merged map (capacity photons)
     size_t capacity = 0;
     void release(bool keepMap) {
-        hipFree(mt); hipFree(halton); hipFree(totalPaths); hipFree(flags); hipFree(localCounts); hipFree(localPhotons); hipFree(stats);
+        hipFree(stateA); hipFree(stateB); hipFree(halton); hipFree(flags); hipFree(localCounts); hipFree(localPhotons); hipFree(stats);
         hipFree(segTask); hipFree(segCount); hipFree(segOff); hipFree(segNshot);
         if (!keepMap) { hipFree(p); hipFree(wi); hipFree(alpha); }
     }
@@ -92,13 +93,16 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     c->prepSeconds[0] = c->prepSeconds[1] = 0.0;
     const uint32_t T = n_tasks;
     const uint32_t blockSize = 4096;
-    // room for one block of one task: spectral splitting stores up to ~3 photons per path.  With very many
-    // virtual tasks (one lane each: the way to fill the chip) the per-task room shrinks to keep the pool within 48 GB;
-    // a task that outgrows it fails the call with PVOL_E_LIMIT rather than dropping photons.
-    const uint32_t cap = (uint32_t)std::min<size_t>(16384, std::max<size_t>(1024, ((size_t)48 << 30) / ((size_t)T * 144)));
+    const size_t SW = pvol_shoot_state_words();
+    // Room for one block of one task.  Spectral splitting stores up to ~3 photons per path but the usual yield is
+    // ~10 photons per 4096-path block, so the pool starts small (T x 256 x 144 B) and a round in which some task outgrew
+    // it is REDONE with a larger one from the saved RNG states (the round is a pure function of them): nothing is dropped
+    // and nothing is sized for the worst case.
+    uint32_t cap = 256;
+    const uint32_t capMax = (uint32_t)std::min<size_t>(16384, std::max<size_t>(256, ((size_t)48 << 30) / ((size_t)T * 144)));
     Buffers B;
-    bool good = ok(hipMalloc(&B.mt, sizeof(uint32_t) * 625 * (size_t)T)) && ok(hipMalloc(&B.halton, sizeof(uint32_t) * 41 * (size_t)T)) &&
-                ok(hipMalloc(&B.totalPaths, sizeof(uint32_t) * T)) && ok(hipMalloc(&B.flags, sizeof(uint32_t) * T)) &&
+    bool good = ok(hipMalloc(&B.stateA, sizeof(uint32_t) * SW * (size_t)T)) && ok(hipMalloc(&B.stateB, sizeof(uint32_t) * SW * (size_t)T)) &&
+                ok(hipMalloc(&B.halton, sizeof(uint32_t) * 48 * (size_t)T)) && ok(hipMalloc(&B.flags, sizeof(uint32_t) * T)) &&
                 ok(hipMalloc(&B.localCounts, sizeof(uint32_t) * 4 * (size_t)T)) &&
                 ok(hipMalloc(&B.localPhotons, sizeof(float) * 36 * (size_t)cap * T)) && ok(hipMalloc(&B.stats, sizeof(unsigned long long) * 8)) &&
                 ok(hipMalloc(&B.segTask, sizeof(uint32_t) * T)) && ok(hipMalloc(&B.segCount, sizeof(uint32_t) * T)) &&
@@ -107,13 +111,15 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     if (!good) { B.release(false); return PVOL_E_NO_MEMORY; }
 
     ShootArgs A;
-    A.scene = c->ds; A.shoot = c->dsh; A.nTasks = T; A.mt = B.mt; A.halton = B.halton; A.totalPaths = B.totalPaths; A.flags = B.flags;
+    A.scene = c->ds; A.shoot = c->dsh; A.nTasks = T; A.stateIn = B.stateA; A.stateOut = B.stateA; A.halton = B.halton; A.flags = B.flags;
     A.localPhotons = B.localPhotons; A.localCounts = B.localCounts; A.cap = cap; A.stats = B.stats; A.init = 1;
     if (!ok(pvol_launch_shoot(&A, 0)) || !ok(hipDeviceSynchronize())) { B.release(false); return PVOL_E_NO_DEVICE; }
     A.init = 0;
+    A.stateOut = B.stateB;
 
     const pvol_params &P = c->params;
     std::vector<uint32_t> flags(T), counts(4 * (size_t)T), segTask, segCount, segOff;
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<float> segNshot;
     flags.assign(T, (P.n_caustic_photons == 0 ? 1u : 0u) | (P.n_indirect_photons == 0 ? 2u : 0u) | (P.n_volume_photons == 0 ? 4u : 0u));
     uint32_t nshot = 0;
@@ -126,10 +132,29 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
         bool anyLive = false;
         for (uint32_t t = 0; t < T; ++t) anyLive = anyLive || !(flags[t] & 8u);
         if (!anyLive) break;
-        if (!ok(pvol_launch_shoot(&A, 0)) || !ok(hipMemcpy(counts.data(), B.localCounts, sizeof(uint32_t) * 4 * (size_t)T, hipMemcpyDeviceToHost))) {
-            rc = PVOL_E_NO_DEVICE;
-            break;
-        }
+        if (!ok(hipMemcpy(B.flags, flags.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice))) { rc = PVOL_E_NO_DEVICE; break; }
+        bool redo = false;
+        do {   // one 4096-path block per live task; redone from the same states if a task's block outgrew the buffer
+            redo = false;
+            unsigned long long rs[8];
+            if (!ok(hipMemset(B.stats, 0, sizeof(rs))) || !ok(pvol_launch_shoot(&A, 0)) ||
+                !ok(hipMemcpy(counts.data(), B.localCounts, sizeof(uint32_t) * 4 * (size_t)T, hipMemcpyDeviceToHost)) ||
+                !ok(hipMemcpy(rs, B.stats, sizeof(rs), hipMemcpyDeviceToHost))) { rc = PVOL_E_NO_DEVICE; break; }
+            uint32_t most = 0;
+            for (uint32_t t = 0; t < T; ++t) if (!(flags[t] & (8u | 4u))) most = std::max(most, counts[4 * (size_t)t]);
+            if (most > cap) {
+                if (most > capMax) { rc = PVOL_E_LIMIT; break; }
+                cap = std::min<uint32_t>(capMax, std::max<uint32_t>(most + most / 4, cap * 4));
+                hipFree(B.localPhotons); B.localPhotons = 0;
+                if (!ok(hipMalloc(&B.localPhotons, sizeof(float) * 36 * (size_t)cap * T))) { rc = PVOL_E_NO_MEMORY; break; }
+                A.localPhotons = B.localPhotons; A.cap = cap;
+                redo = true;
+                continue;
+            }
+            for (int i = 0; i < 8; ++i) st[i] += rs[i];
+        } while (redo);
+        if (rc != PVOL_OK) break;
+        { const uint32_t *tmp = A.stateIn; A.stateIn = A.stateOut; A.stateOut = const_cast<uint32_t *>(tmp); }   // the round stands
         // merge in task order (photonshooter.cpp:280-351)
         segTask.clear(); segCount.clear(); segOff.clear(); segNshot.clear();
         for (uint32_t t = 0; t < T; ++t) {
@@ -157,7 +182,6 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
                 if (nCaustic >= P.n_caustic_photons) fl |= 1u;
             }
             if (!(fl & 4u)) {
-                if (lc[0] > cap) { rc = PVOL_E_LIMIT; abortTasks = true; fl |= 8u; continue; }
                 if (lc[0]) {
                     segTask.push_back(t); segCount.push_back(lc[0]); segOff.push_back((uint32_t)nVolume); segNshot.push_back(float(nshot));
                     nVolume += lc[0];
@@ -179,10 +203,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
             if (!g2) { rc = PVOL_E_NO_DEVICE; break; }
         }
         if (rc == PVOL_E_LIMIT || rc == PVOL_E_NO_DEVICE) break;
-        if (!ok(hipMemcpy(B.flags, flags.data(), sizeof(uint32_t) * T, hipMemcpyHostToDevice))) { rc = PVOL_E_NO_DEVICE; break; }
     }
-    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    hipMemcpy(st, B.stats, sizeof(st), hipMemcpyDeviceToHost);
     // paths, follow_calls, no_hit, march_steps, interactions, absorbed, stored_volume, caustic, direct, indirect, split_children, nshot
     c->shootStats[0] = st[0]; c->shootStats[1] = st[1]; c->shootStats[2] = st[2]; c->shootStats[3] = st[3]; c->shootStats[4] = st[4];
     c->shootStats[5] = st[5]; c->shootStats[6] = nVolume; c->shootStats[7] = nCaustic; c->shootStats[8] = nDirect; c->shootStats[9] = nIndirect;

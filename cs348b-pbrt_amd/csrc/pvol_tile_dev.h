@@ -11,28 +11,6 @@
 // The rays it writes carry rng_skip = the sampler's draws in front of the pixel's first sample, so the batch is
 // also a valid input of every other Li kernel.
 
-// draw j of the next `cnt` (<= 64) draws lands in lane j; the stream advances by cnt
-__device__ __forceinline__ uint32_t rng_bulk(Rng &r, int cnt, int lane) {
-    uint32_t out = 0u;
-    int done = 0;
-    r.draws += (unsigned long long)cnt;
-    while (done < cnt) {
-        if (r.mti >= MT_N) { mt_regenerate(r.mt, lane); r.mti = 0; }
-        const int take = min(cnt - done, MT_N - r.mti);
-        if (lane >= done && lane < done + take) {
-            uint32_t y = r.mt[r.mti + lane - done];
-            y ^= (y >> 11);
-            y ^= (y << 7) & 0x9d2c5680u;
-            y ^= (y << 15) & 0xefc60000u;
-            y ^= (y >> 18);
-            out = y;
-        }
-        r.mti += take;
-        done += take;
-    }
-    return out;
-}
-
 // core/montecarlo.h:289-293
 __device__ __forceinline__ float sobol2(uint32_t n, uint32_t scramble) {
     for (uint32_t v = 1u << 31; n != 0; n >>= 1, v ^= v >> 1)

@@ -80,8 +80,7 @@ public:
         flattenVolume(scene->volumeRegion, &s.volume);
         for (size_t i = 0; i < scene->lights.size(); ++i) lights.push_back(flattenLight(scene->lights[i]));
         // fully refined primitives of the aggregate (the configs use GeometricPrimitive(Triangle, matte|glass))
-        vector<Reference<Primitive> > todo, leaves;
-        todo.push_back(Reference<Primitive>(scene->aggregate));
+        vector<Reference<Primitive> > leaves;
         scene->aggregate->FullyRefine(leaves);
         for (size_t i = 0; i < leaves.size(); ++i) {
             const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(leaves[i].GetPtr());
@@ -109,7 +108,12 @@ public:
         int rc = pvol_set_scene(ctx, &s);
         if (rc != PVOL_OK) Severe("photonvolume_hip: %s", pvol_strerror(rc));
         // photon shoot + search-structure build on the device; NumSystemCores() virtual tasks would mimic a
-        // CPU run, a GPU wants thousands
+        // CPU run, a GPU wants thousands.
+        // NOTE: an unchanged SamplerRenderer still runs the reference's own PhotonShooter::Preprocess when the SURFACE
+        // integrator is "photonmap" (core/api.cpp:1225-1230, samplerrenderer.cpp:194-196), so its CPU shooter also fills a
+        // volume map nobody reads; set that integrator's "volumephotons" to 0 in the scene (the shooter's volume store is
+        // driven by the VolumeIntegrator's parameter of the same name) or see INTEGRATION.md for taking the map from it
+        // with pvol_upload_photons instead of shooting here.
         rc = pvol_preprocess(ctx, 16384);
         if (rc == PVOL_E_SHOOT_FAILED) Error("Unable to store enough photons.  Giving up.\n");   // photonshooter.cpp:292
         else if (rc != PVOL_OK) Severe("photonvolume_hip: %s", pvol_strerror(rc));

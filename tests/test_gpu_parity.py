@@ -191,7 +191,10 @@ def test_gather_properties_at_scale(pvol, orc):
     pv = _ctx(pvol, s, params, (P, W, A))
     out1, d1 = pv.li(rays, streams.copy())
     out1b, d1b = pv.li(rays, streams.copy())
-    assert (out1 == out1b).all() and (d1 == d1b).all()          # deterministic / idempotent
+    # idempotent: same k-NN sets, same draw counts; the ORDER of the flux additions may differ between runs (which lookups the
+    # group kernel hands to its exact-lookup pass depends on the radius guesses, i.e. on wave scheduling): fp32 rounding only
+    assert (d1 == d1b).all()
+    np.testing.assert_allclose(out1, out1b, rtol=5e-6, atol=1e-7 * float(np.abs(out1).max()))
     pv.upload_photons(P, W, 2 * A)
     out2, _ = pv.li(rays, streams.copy())
     pv0 = _ctx(pvol, s, params, None)

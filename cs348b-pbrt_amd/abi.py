@@ -87,7 +87,8 @@ class Stats(C.Structure):
                 ("n_shadow_unoccluded", C.c_uint64), ("n_guess_retries", C.c_uint64),
                 ("cy_search", C.c_uint64), ("cy_select", C.c_uint64), ("cy_flux", C.c_uint64),
                 ("cy_total", C.c_uint64), ("group_guess_failed", C.c_uint64), ("group_plan_skipped", C.c_uint64),
-                ("cy_fallback", C.c_uint64)]
+                ("cy_fallback", C.c_uint64), ("group_deferred_overflow", C.c_uint64), ("group_deferred_too_few", C.c_uint64),
+                ("group_attempts", C.c_uint64)]
 
 
 # numpy views of the two array-of-struct inputs (sizes checked against pvol.h in the tests)

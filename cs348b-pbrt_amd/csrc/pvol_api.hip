@@ -528,7 +528,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
             // room for the lookups the bucket plan hands over (a fraction of a percent of ~40 per ray on C2); a list that
             // overflows raises needSeq and the batch is redone sequentially, never truncated
-            const size_t wantDefer = (size_t)nRays / 4 + 65536;
+            const size_t wantDefer = (size_t)nRays / 2 + 65536;
             if (wantDefer > c->deferCap) {
                 hipStreamSynchronize(stream);   // an earlier batch may still read the old list
                 if (c->dDefer) hipFree(c->dDefer);
@@ -703,6 +703,7 @@ int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
     out->n_lookups_lt10 = h.nLookupsLt10; out->n_shadow_unoccluded = h.nShadowUnoccluded;
     out->n_guess_retries = h.pad;
     out->group_guess_failed = h.diag[0]; out->group_plan_skipped = h.diag[1]; out->cy_fallback = h.diag[2];
+    out->group_deferred_overflow = h.diag[3]; out->group_deferred_too_few = h.diag[4]; out->group_attempts = h.diag[5];
     out->cy_search = h.cySearch; out->cy_select = h.cySelect; out->cy_flux = h.cyFlux; out->cy_total = h.cyTotal;
     if (reset && !ok(hipMemset(c->dCounters, 0, sizeof(DevCounters)))) return PVOL_E_NO_DEVICE;
     return PVOL_OK;

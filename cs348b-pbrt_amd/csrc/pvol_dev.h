@@ -105,7 +105,7 @@ struct DevShootScene {
 struct DevCounters {
     unsigned long long nRays, nSteps, nTested, nKept, nLookupsLt10, nShadowUnoccluded, nErrors, pad;
     unsigned long long cySearch, cySelect, cyFlux, cyTotal;  // s_memtime cycles summed over waves (stats build only)
-    unsigned long long diag[3];   // li_group_kernel (stats build): lookups whose radius guess failed / whose bucket plan was skipped / cycles spent in the exact fallback lookups
+    unsigned long long diag[6];   // li_group_kernel (stats build): lookups whose radius guess failed / whose bucket plan was skipped / cycles spent in the exact fallback lookups
 };
 
 // Tile driver (pvol_tile_dev.h, pvol_tile.hip): what a SamplerRendererTask needs besides the scene.

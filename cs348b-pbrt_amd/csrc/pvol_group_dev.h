@@ -279,7 +279,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     const int k = S.nUsed;
     const float wIso = 1.f / (4.f * K_PI);
     const bool useLiiAny = (ySa1 != 0.0 || ySs1 != 0.0) && !blackS1;   // L_ii reaches the result at all (photonvolume.cpp:208-211)
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     const float *bX = L.pos, *bY = L.pos + GRP_PITCH, *bZ = L.pos + 2 * GRP_PITCH, *bI = L.pos + 3 * GRP_PITCH;
     uint32_t *histLane = L.hist + lane;
@@ -292,7 +292,20 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
         const int nIn = (int)min((unsigned long long)GRP_CH, (unsigned long long)A.nRays - r0);
         // ---- order the chunk's rays by scatter offset: lanes of a group then march in near lock-step positions
         __syncthreads();
-        for (int i = lane; i < GRP_CH; i += LANES) L.ubuf[i] = i < nIn ? A.rays[r0 + i].scatter_u : 3.f;
+        // key = step count + scatter offset: rays of one pixel whose lengths straddle a step-count boundary march with
+        // different step lengths and drift apart by up to a step; keeping equal counts together keeps the groups compact
+        for (int i = lane; i < GRP_CH; i += LANES) {
+            float key = 3.0e9f;
+            if (i < nIn) {
+                const pvol_ray kr = A.rays[r0 + i];
+                RayD rr;
+                rr.o = v3(kr.o[0], kr.o[1], kr.o[2]); rr.d = v3(kr.d[0], kr.d[1], kr.d[2]); rr.mint = kr.mint; rr.maxt = kr.maxt;
+                float ka = 0.f, kb = 0.f;
+                const bool kh = S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, rr, &ka, &kb) && (kb - ka) != 0.f;
+                key = (kh ? ceilf((kb - ka) / S.stepSize) : 0.f) + kr.scatter_u;
+            }
+            L.ubuf[i] = key;
+        }
         __syncthreads();
         for (int i = lane; i < nIn; i += LANES) {
             const float ui = L.ubuf[i];
@@ -435,6 +448,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         if (!(guessBase > 0.f)) guessBase = nbr > 0.f ? nbr : S.rkEstimate;
                     }
                     float Twant = need ? ((guessBase * A.grpGuess < S.maxDistSq) ? guessBase * A.grpGuess : S.maxDistSq) : 0.f;
+                    int lastFail = 0;   // stats: 1 = bucket overflow, 2 = too few photons inside the radius, 3 = other
                     for (int attempt = 0; attempt < 3; ++attempt) {
                         bool needP = need && !done && Twant > 0.f;
                         if (!__ballot(needP)) break;
@@ -453,17 +467,32 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         float hx = needP ? p.x : -big, hy = needP ? p.y : -big, hz = needP ? p.z : -big;
                         lx = -wave_max(-lx); ly = -wave_max(-ly); lz = -wave_max(-lz);
                         hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
-                        const V3 c = v3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
+                        V3 c = v3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
                         float rho = needP ? len(p - c) : 0.f;
                         rho = wave_max(rho);
+                        if (attempt < 2 && rho > 0.3f * sqrtf(T)) {
+                            // the query points are spread over a good part of the search radius (rays that march with different step
+                            // lengths): serve the half below the centre along the widest axis now, the rest in the next attempt
+                            const float ex = hx - lx, ey = hy - ly, ez = hz - lz;
+                            const float side = (ex >= ey && ex >= ez) ? p.x - c.x : (ey >= ez ? p.y - c.y : p.z - c.z);
+                            needP = needP && !(side > 0.f);
+                            T = wave_max(needP ? Tl : 0.f);
+                            lx = needP ? p.x : big; ly = needP ? p.y : big; lz = needP ? p.z : big;
+                            hx = needP ? p.x : -big; hy = needP ? p.y : -big; hz = needP ? p.z : -big;
+                            lx = -wave_max(-lx); ly = -wave_max(-ly); lz = -wave_max(-lz);
+                            hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+                            c = v3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
+                            rho = wave_max(needP ? len(p - c) : 0.f);
+                        }
                         const float Rs = (sqrtf(T) + rho) * 1.0001f + 1e-6f;   // superset by the triangle inequality, with rounding slack
                         unsigned long long tst = 0, ts0 = STATS ? stamp() : 0ull;
                         __syncthreads();   // the U region changes hands: mini lists -> paint list
                         const int Mb = stage_bucket(S, G, L.pos, c, Rs, lane, tst);
                         if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; }
+                        if (STATS) wc.diag5 += 1;
                         if (Mb < 0) {   // bucket overflow
                             if (STATS) wc.diag1 += __popcll(__ballot(needP));
-                            if (needP) Twant = 0.4f * Tl;
+                            if (needP) { Twant = 0.4f * Tl; lastFail = 1; }
                             continue;
                         }
                         // the bucket covers more than this lane asked for when other lanes asked for more: take it (up to
@@ -518,6 +547,10 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         if (STATS && attempt == 0) wc.diag0 += __popcll(__ballot(needP && !ok && !shortSet));
                         if (needP) {   // what to ask for next time (0 = nothing: crowded bin or wrapped counter, the exact lookup takes it)
                             Twant = 0.f;
+                            lastFail = tooFew ? 2 : 3;
+                            // crowded bin (more values than the mini list ranks) or a wrapped counter: a radius that ends just behind
+                            // the k-th's bin still holds k photons and spreads them over finer bins
+                            if (!tooFew && !ok && !shortSet) Twant = (sane && bstarI >= 0) ? Tl * ((float)(bstarI + 1) * (1.f / GRP_BINS)) * 1.001f : 0.6f * Tl;
                             if (tooFew) {   // the count seen inside Tl gives the local density: k photons need ~ (k / count)^(2/3) x Tl
                                 const float grow = cum > 0 ? 1.35f * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf((float)k / (float)cum)) : 1.0e9f;
                                 Twant = fminf(S.maxDistSq, Tl * fmaxf(1.5f, grow));
@@ -644,13 +677,14 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             if (at < A.deferCap) {
                                 DeferRec r;
                                 r.ray = (uint32_t)ri; r.px = p.x; r.py = p.y; r.pz = p.z; r.kRem = kRem; r.stepD = stepD;
-                                r.guess = guessBase > 0.f ? guessBase : 0.f; r.pad = 0u;
+                                // the radius^2 the next attempt would have asked for is the best guess there is (lphoton widens it by 1.3)
+                                r.guess = Twant > 0.f ? Twant * (1.f / PVOL_GUESS_SCALE) : (guessBase > 0.f ? guessBase : 0.f); r.pad = 0u;
                                 A.defer[at] = r;
                             } else {
                                 atomicOr(A.needSeq, 1u);   // list full: the batch is redone by the sequential kernel, never dropped
                             }
                         }
-                        if (STATS) wc.retries += nfb;
+                        if (STATS) { wc.retries += nfb; wc.diag3 += __popcll(__ballot(need && !done && lastFail == 1)); wc.diag4 += __popcll(__ballot(need && !done && lastFail == 2)); }
                     }
                     // a k-th distance exists only for full sets; a short set says "search the full radius here"
                     const float rkGuess = (need && done) ? (nFoundLane >= k ? rk : S.maxDistSq) : 0.f;
@@ -776,7 +810,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_fixup_kernel(LiArgs A) {
     const f4 sigT4 = sigA4 + sigS4;
     const f4 albedo4 = clean4(fdiv4(sigS4, sigT4), q);
     const f4 X4 = ld4(S.cieX, q), Y4 = ld4(S.cieY, q), Z4 = ld4(S.cieZ, q);
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const DeferRec r = A.defer[e];
@@ -804,6 +838,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_fixup_kernel(LiArgs A) {
         }
     }
     wc.rays = 0; wc.steps = 0;   // the march steps were counted by li_group_kernel
+    if (STATS) { wc.diag2 = stamp() - tk0; wc.cySearch = wc.cySelect = wc.cyFlux = 0; tk0 = stamp(); }   // this kernel's cycles are reported on their own
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
 

@@ -51,7 +51,7 @@ struct Gather {
     int cap;
 };
 // per-wave work counters (stats build), flushed with one atomic each when the wave retires
-struct WaveCounters { unsigned long long tested, kept, lt10, retries, cySearch, cySelect, cyFlux, rays, steps, unocc, diag0, diag1, diag2; };
+struct WaveCounters { unsigned long long tested, kept, lt10, retries, cySearch, cySelect, cyFlux, rays, steps, unocc, diag0, diag1, diag2, diag3, diag4, diag5; };
 __device__ __forceinline__ unsigned long long stamp() { return __builtin_amdgcn_s_memtime(); }
 
 // Keep the k nearest of the M > k candidates of the LDS list; returns the k-th smallest dist^2 (the new
@@ -245,10 +245,11 @@ __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, i
                 if (STATS) tested += segLen;
             }
         }
-        if (guessed && count < k) {   // the guessed radius held fewer than k photons: search the full radius
-            if (STATS) wc.retries += 1;
-            T = S.maxDistSq;
-            guessed = false;
+        if (guessed && count < k) {   // the guessed radius held fewer than k photons: grow it by what the count seen says about
+            if (STATS) wc.retries += 1;   // the local density (k photons need ~ (k / count)^(2/3) x T), up to the full radius
+            const float grow = count > 0 ? 1.35f * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf((float)k / (float)count)) : 1.0e9f;
+            T = fminf(S.maxDistSq, T * fmaxf(2.f, grow));
+            guessed = T < S.maxDistSq;
             continue;
         }
         break;
@@ -919,6 +920,7 @@ __device__ __forceinline__ void flush_counters(DevCounters *c, const WaveCounter
         atomicAdd(&c->cyFlux, wc.cyFlux);
         atomicAdd(&c->cyTotal, stamp() - t0);
         atomicAdd(&c->diag[0], wc.diag0); atomicAdd(&c->diag[1], wc.diag1); atomicAdd(&c->diag[2], wc.diag2);
+        atomicAdd(&c->diag[3], wc.diag3); atomicAdd(&c->diag[4], wc.diag4); atomicAdd(&c->diag[5], wc.diag5);
     }
 }
 
@@ -957,7 +959,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
         rng.mti = MT_N;
         rng_skip<true>(rng, st.start_draw, lane);
     }
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     for (uint32_t k = 0; k < st.n_rays; ++k) {
         const size_t ri = (size_t)st.first_ray + k;
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     Rng rng;
     rng.mt = 0;
     rng.mti = 0;
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     for (;;) {
         uint32_t chunk = 0;
@@ -1083,7 +1085,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_resolve_kernel(LiArgs A) {
         rng.draws = (A.sliceK == 0) ? st.start_draw : st.end_draw;
         __syncthreads();
     }
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     const bool grid = (S.volKind == PVOL_VOLUME_GRID);
     const uint32_t end = min(st.n_rays, begin + A.sliceM);
     for (uint32_t k = begin; k < end; ++k) {
@@ -1127,7 +1129,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     rng.mt = 0;
     rng.mti = 0;
     rng.draws = 0;
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     const bool grid = (S.volKind == PVOL_VOLUME_GRID);
     const uint32_t chunksPerSlice = (A.sliceM + CHUNK_RAYS - 1) / CHUNK_RAYS;

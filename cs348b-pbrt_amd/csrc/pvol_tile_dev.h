@@ -265,7 +265,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
         rng.draws = st.end_draw;
         __syncthreads();
     }
-    WaveCounters wc = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    WaveCounters wc = {};
     const bool grid = (S.volKind == PVOL_VOLUME_GRID);
     const uint32_t end = min(st.n_rays, begin + A.sliceM);
     const int4 w = T.windows[sidx];

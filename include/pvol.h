@@ -177,7 +177,10 @@ typedef struct pvol_stats {
     uint64_t cy_total;         /* ... whole kernel                                                        */
     uint64_t group_guess_failed;  /* li_group_kernel: lookups whose guessed search radius was too small or too large ...   */
     uint64_t group_plan_skipped;  /* ... whose shared photon bucket overflowed (or k outside the plan) ...                 */
-    uint64_t cy_fallback;         /* ... and the cycles of the exact wave-cooperative lookups that served both (n_guess_retries counts them) */
+    uint64_t cy_fallback;         /* ... and the cycles of li_fixup_kernel, whose exact wave-cooperative lookups serve what the plan handed over (n_guess_retries counts them) */
+    uint64_t group_deferred_overflow;  /* handed-over lookups whose last attempt ended in a bucket overflow ...                */
+    uint64_t group_deferred_too_few;   /* ... or found fewer than k photons inside a radius below the maximum                  */
+    uint64_t group_attempts;           /* shared-bucket attempts (stagings), per wavefront                                     */
 } pvol_stats;
 
 /* ---- tile driver, SURVEY 8(f)-1: the caller of Li() (LD sampler, perspective camera) and its

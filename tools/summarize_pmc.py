@@ -25,7 +25,7 @@ for d in sorted(glob.glob(os.path.join(g, tag + "_pmc_*"))):
         continue
     f = max(files, key=os.path.getmtime)   # gpurun merges runs: keep the newest pass only
     for r in csv.DictReader(open(f)):
-        if "li_group_kernel" in r["Kernel_Name"] or "li_par_kernel" in r["Kernel_Name"]:
+        if "li_group_kernel" in r["Kernel_Name"]:   # the dominant kernel only (li_fixup_kernel's share is in the kernel trace)
             agg[r["Counter_Name"]] += float(r["Counter_Value"])
             kernels.add(r["Kernel_Name"].split("<")[0].replace("void ", ""))
 plain = None
@@ -47,8 +47,10 @@ if agg and plain:
         "kernel_avg_ms_under_pmc": plain["kernel_avg_ms"],
     }
     json.dump(summary, open(os.path.join(out, tag + "_pmc_summary.json"), "w"), indent=1)
-    json.dump({"hbm_bytes_per_ray": hbm / rays,
-               "source": "profiles/%s_pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 / rays, rocprofv3 --pmc passes of tools/pvol_prof" % tag},
+    json.dump({"kernel": "li_group_kernel", "hbm_bytes_per_ray": hbm / rays, "valu_insts_per_ray": agg.get("SQ_INSTS_VALU", 0) / rays,
+               "salu_insts_per_ray": agg.get("SQ_INSTS_SALU", 0) / rays,
+               "waves_per_simd": 3, "vgprs": 168,
+               "source": "profiles/%s_pmc_summary.json: SQ_INSTS_VALU / rays and (2*FETCH_SIZE + WRITE_SIZE)*1024 / rays, rocprofv3 --pmc passes of tools/pvol_prof on the bench's scene and device-shot map at 640x360, 256 spp" % tag},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("hbm bytes/ray %.0f, L2 hit %.3f, VALU insts/ray %.0f" % (hbm / rays, summary["l2_hit_rate"], agg.get("SQ_INSTS_VALU", 0) / rays))
 _ks = glob.glob(os.path.join(g, tag + "_trace", "*", "*kernel_stats.csv"))

@@ -287,58 +287,47 @@ __device__ f4 vol_tau(const DevScene &S, const RayD &r, float stepSize, float u,
     return sigT * dsum * stepSize;
 }
 
-// volumes/rainbow.cpp:41-78 in the float4 layout
-__device__ __forceinline__ float lerp_or_zero(float theta, float minT, float maxT, float sw, float ew) {
-    if (theta < minT || maxT < theta) return 0;
-    const float thetaRange = maxT - minT;
-    const float wavelengthRange = ew - sw;
-    return sw + (theta - minT) * wavelengthRange / thetaRange;
-}
-__device__ __forceinline__ float lerp_transfer(float x, float xMin, float xMax, float y0, float y1) {
-    if (x < xMin) return y0;
-    if (xMax < x) return y1;
-    const float thetaRange = xMax - xMin;
-    const float range = y1 - y0;
-    return y0 + (x - xMin) * range / thetaRange;
-}
-__device__ f4 rainbow_reflection(f4 spectrum, V3 w, V3 wi, int q) {
-    float cosTheta = dot(wi, -w);
-    const float radToDeg = 57.2957;
-    float theta = radToDeg * acosf(cosTheta);
-    float I = (0.5f + 4.5f * powf(0.5 * (1.f + dot(wi, -w)), 8.f)) / (4.f * K_PI);  // PhaseMieHazy core/volume.cpp:138-141
-    float innerGlow = lerp_transfer(theta, 40.4, 40.45, 1.0, 0.9);
-    I *= innerGlow;
-    float rainbowI = 1.0f;
-    float primaryRainbowI = 0.92f;
-    float secondaryRainbowI = 0.42 * primaryRainbowI;
-    float mistI = 0.08f;
-    float lambda = lerp_or_zero(theta, 40.4, 42.3, 400.0, 700.0);
-    if (lambda) {
-        rainbowI *= primaryRainbowI;
-    } else {
-        lambda = lerp_or_zero(theta, 51.0, 54.4, 700.0, 400.0);
-        if (lambda) rainbowI *= secondaryRainbowI;
+// RainbowVolume::rainbowReflection (volumes/rainbow.cpp:41-78): the direct term of the rainbow medium is the Mie-hazy phase
+// intensity times (a mist fraction of the light + the slice of its spectrum the bow puts at this phase angle).  Float4
+// form: lane q holds bins 4q..4q+3.  The two bows are rows of a table -- phase-angle band in degrees, the wavelength ramp
+// across it in nm, intensity gain -- looked up without branches; CoefficientSpectrum::filter (core/spectrum.h:300-320)
+// becomes two per-bin weights.  Every product keeps the reference's operand order (the outputs are compared with its records).
+struct BowBand { float theta0, theta1, lambda0, lambda1, gain; };
+__device__ f4 rainbow_reflection(f4 Ld, V3 w, V3 wi, int q) {
+    const BowBand bows[2] = {{40.4f, 42.3f, 400.f, 700.f, 0.92f},                       // primary
+                             {51.0f, 54.4f, 700.f, 400.f, (float)(0.42 * 0.92f)}};      // secondary: 42 % of the primary
+    const float mist = 0.08f;
+    const float cosTheta = dot(wi, -w);
+    const float theta = 57.2957f * acosf(cosTheta);
+    // PhaseMieHazy (core/volume.cpp:138-141), dimmed by 10 % across the bow's inner edge (40.4 .. 40.45 degrees)
+    float I = (0.5f + 4.5f * powf(0.5 * (1.f + cosTheta), 8.f)) / (4.f * K_PI);
+    const float e0 = 40.4f, e1 = 40.45f, g0 = 1.0f, g1 = 0.9f;
+    const float ramp = g0 + (theta - e0) * (g1 - g0) / (e1 - e0);
+    I *= theta < e0 ? g0 : (e1 < theta ? g1 : ramp);
+    float lambda = 0.f, gain = 1.0f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const BowBand B = bows[b];
+        const float l = B.lambda0 + (theta - B.theta0) * (B.lambda1 - B.lambda0) / (B.theta1 - B.theta0);
+        const bool hit = lambda == 0.f && !(theta < B.theta0 || B.theta1 < theta) && l != 0.f;
+        lambda = hit ? l : lambda;
+        gain = hit ? 1.0f * B.gain : gain;
     }
-    if (!lambda) return spectrum * (I * mistI);   // I * mistI * spectrum
-    // CoefficientSpectrum::filter, core/spectrum.h:300-320
-    float deltaLambda = float(700 - 400) / 30;
-    float indexWithDecimals = (lambda - 400) / deltaLambda;
-    int index = int(indexWithDecimals);
-    float t = indexWithDecimals - index;
-    float sp[4] = {spectrum.x, spectrum.y, spectrum.z, spectrum.w};
-    float rb[4];
+    if (lambda == 0.f) return Ld * (I * mist);
+    // filter(lambda): bin `index` keeps the fraction t of the light, bin index + 1 the fraction 1 - t
+    const float pos = (lambda - 400) / (float(700 - 400) / 30);
+    const int index = int(pos);
+    const float t = pos - index;
+    const int first = 4 * q;
+    const float in[4] = {Ld.x, Ld.y, Ld.z, Ld.w};
+    float bow[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int bin = 4 * q + c;
-        float v = 0.f;
-        if (index >= 0 && index < 30) {
-            if (bin == index) v = sp[c] * t;
-            if (bin == index + 1 && index + 1 < 30) v = sp[c] * (1 - t);
-        }
-        rb[c] = v;
+        const int bin = first + c;
+        const float wgt = (bin == index) ? t : ((bin == index + 1 && bin < 30) ? (1 - t) : -1.f);
+        bow[c] = (wgt >= 0.f && index >= 0 && index < 30) ? in[c] * wgt : 0.f;
     }
-    f4 rainbow = make_float4(rb[0], rb[1], rb[2], rb[3]);
-    return (spectrum * mistI + rainbow * rainbowI) * I;
+    return (Ld * mist + make_float4(bow[0], bow[1], bow[2], bow[3]) * gain) * I;
 }
 
 #endif

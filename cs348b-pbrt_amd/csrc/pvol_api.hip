@@ -537,7 +537,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
                 c->deferCap = wantDefer;
             }
             a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
-            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, (uint32_t)c->nCU * 8u, stream);
+            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, (uint32_t)c->nCU * 8u, 0, stream);
             c->lastKernel = "li_group_kernel";
         } else {
             c->lastKernel = "li_par_kernel";
@@ -552,12 +552,37 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         e = hipSuccess;
         unsigned long long chunks = (unsigned long long)((sliceM + 63) / 64) * nStreams;
         uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
+        // li_group_kernel's replay form (one ray per lane, shared photon bucket) where no march step can reach the roulette, the
+        // medium is isotropic and a photon map exists; li_replay_kernel (one wave per ray) otherwise, and as the gated backup
+        const bool gridVol = c->hs.volKind == PVOL_VOLUME_GRID;
+        int groupForm = 0;
+        if (!c->noGroup && !c->statsOn && !roulette_possible(c) && c->hs.g == 0.f && c->hs.nPhotons > 0 && c->hs.nUsed >= 10 &&
+            (c->hs.volKind == PVOL_VOLUME_HOMOGENEOUS || gridVol))
+            groupForm = gridVol ? 2 : 1;
+        uint32_t gWaves = 0;
+        if (groupForm) {
+            const unsigned long long gchunks = (unsigned long long)((sliceM + 511) / 512) * nStreams;
+            gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
+            // hand-over list: nused beyond the bucket plan sends every dense lookup to the exact pass (C3: ~14 per ray)
+            const size_t perSlice = (size_t)sliceM * nStreams;
+            size_t wantDefer = (c->hs.nUsed > 100 ? perSlice * 24 : perSlice / 2) + 65536;
+            wantDefer = std::min<size_t>(wantDefer, ((size_t)8 << 30) / sizeof(DeferRec));
+            if (wantDefer > c->deferCap) {
+                hipStreamSynchronize(stream);
+                if (c->dDefer) hipFree(c->dDefer);
+                c->dDefer = 0; c->deferCap = 0;
+                if (!ok(hipMalloc(&c->dDefer, wantDefer * sizeof(DeferRec)))) return PVOL_E_NO_MEMORY;
+                c->deferCap = wantDefer;
+            }
+            a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
+            c->lastKernel = "li_group_kernel";
+        }
         for (uint32_t k = 0; k < nSlices && ok(e); ++k) {
             a.sliceK = k;
-            hipMemsetAsync(c->dWords, 0, 2 * sizeof(uint32_t), stream);
+            hipMemsetAsync(c->dWords, 0, 4 * sizeof(uint32_t), stream);
             if (tile) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true), c->hs.candCap, stream);
             if (ok(e)) e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream,
-                                                tile == 0);
+                                                tile == 0, groupForm, pvol_group_lds_bytes(c->hs.candCap), gWaves, (uint32_t)c->nCU * 8u);
         }
     } else {
         c->lastKernel = "li_seq_kernel";

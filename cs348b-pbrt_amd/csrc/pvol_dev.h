@@ -76,7 +76,7 @@ struct DeferRec {
     float kRem;       // -log2(e) * optical length behind the step
     float stepD;      // step length x density factor
     float guess;      // a k-th distance^2 nearby, 0 = none
-    uint32_t pad;
+    float dens;       // density factor at the point (1 inside a homogeneous extent)
 };
 
 // What only the photon shooter reads (core/photonshooter.cpp): surface materials, emission frames,

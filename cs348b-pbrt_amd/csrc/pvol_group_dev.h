@@ -36,6 +36,15 @@
 #define GRP_TRI_ROWS 8   // scenes with a distant light and at most this many triangles test shadow rays against precomputed rows
 #define GRP_WPE 3     // waves per SIMD the register allocation must leave room for
 #define GRP_U_BYTES 4096   // shared scratch: stage paint list | histogram | chunk ordering | mini lists (never live together)
+#define GRP_PLAN_KMAX 100  // nused above this: the bucket (GRP_CAP photons) cannot hold a k-NN ball, only the "all photons inside maxDist" case
+// Two more template switches widen the kernel beyond C2:
+//   REPLAY  scenes where drawn VALUES reach the result (> 1 light: the per-step light choice; VolumeGrid: the tau() offsets): the
+//           rays come slice by slice with the per-step records of the RNG pre-pass (pvol_march.hip: li_geo / li_resolve_lite /
+//           li_resolve / the fused tile pre-pass), one record slot per ray, and the kernel neither counts draws nor touches streams;
+//   GRID    VolumeGridDensity (volumes/volumegrid.cpp:39-57): trilinear density per lane, DensityRegion::tau (core/volume.cpp:
+//           296-310) stepped per lane with the recorded offsets.  tau_b = sigma_t_b x (a scalar), so the forward formulation holds.
+// nused > GRP_PLAN_KMAX (C3: 500) keeps only the fixed-radius plan: when everything within maxDist fits the bucket the lanes
+// with fewer than nused photons are served here (most of C3's lookups: < 10 photons -> 0), the dense ones go to li_fixup_kernel.
 
 struct GroupLds {
     float *pos;             // bucket, SoA: x[GRP_PITCH] | y | z | photon index bits
@@ -45,7 +54,26 @@ struct GroupLds {
     unsigned short *order;  // GRP_CH: chunk-local ray index by rank of scatter offset
     float *cst;             // 9 x 32 floats: sigA, sigS, le, albedo, light-0 intensity, 1/sigS, CIE X, Y, Z weights
     float *trows;           // GRP_TRI_ROWS x 16 floats: per-triangle shadow-ray precomputation for a distant light
+    float *lint;            // PVOL_MAX_LIGHTS x 32 floats: every light's intensity spectrum (REPLAY: the light differs per lane and step)
 };
+
+// DensityRegion::tau (core/volume.cpp:296-310) of o + t d, t in [mint, maxt], for ONE lane: the scalar L with tau_b = sigma_t_b * L
+// (sum of densities x step; the reference adds sigma_t * density per sample, the same up to rounding)
+__device__ float grid_tau_lane(const DevScene &S, V3 o, V3 d, float mint, float maxt, float stepSize, float u) {
+    const float length = len(d);
+    if (length == 0.f) return 0.f;
+    RayD rn;
+    rn.o = o; rn.d = vdiv(d, length); rn.mint = mint * length; rn.maxt = maxt * length;
+    float t0, t1;
+    if (!vol_intersect(S, rn, &t0, &t1)) return 0.f;
+    float dsum = 0.f;
+    t0 += u * stepSize;
+    while (t0 < t1) {
+        dsum += grid_density(S, xform_point(S.w2v, rn.o + rn.d * t0));
+        t0 += stepSize;
+    }
+    return dsum * stepSize;
+}
 
 // Photons within Rs of c -> LDS bucket.  Returns the count, or -1 if the bucket would overflow.
 __device__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
@@ -229,7 +257,7 @@ __device__ __forceinline__ uint32_t nib_sum(uint32_t w) {   // sum of the eight 
     return (t * 0x01010101u) >> 24;
 }
 
-template <bool STATS, bool SPECTRAL>
+template <bool STATS, bool SPECTRAL, bool REPLAY, bool GRID>
 __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
@@ -248,6 +276,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     L.ubuf = reinterpret_cast<float *>(U);
     L.cst = reinterpret_cast<float *>(U + GRP_U_BYTES);
     L.trows = L.cst + 9 * 32;
+    L.lint = L.trows + GRP_TRI_ROWS * 16;
     for (int i = lane; i < PREV_N; i += LANES) prevRk[i] = 0.f;
     const int q = lane & 7;
     const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
@@ -256,7 +285,9 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     const int nLights = S.nLights;
     const float ySa1 = spec_y(sigA4, Y4), ySs1 = spec_y(sigS4, Y4);
     const bool blackS1 = spec_is_black(sigS4);
-    const bool lightBlack = nLights > 0 ? spec_is_black(ld4(S.lights[0].intensity, q)) : true;
+    unsigned int lightBlackMask = 0u;   // lights whose intensity spectrum is black
+    for (int l = 0; l < nLights; ++l) if (spec_is_black(ld4(S.lights[l].intensity, q))) lightBlackMask |= 1u << l;
+    if (REPLAY) for (int i = lane; i < PVOL_MAX_LIGHTS * 32; i += LANES) L.lint[i] = ((i >> 5) < nLights && (i & 31) < 30) ? S.lights[i >> 5].intensity[i & 31] : 0.f;
     float sigTmax = fmaxf(fmaxf(sigT4.x, sigT4.y), fmaxf(sigT4.z, sigT4.w));
     sigTmax = wave_max(sigTmax);
     if (lane < 32) {
@@ -274,11 +305,15 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     __syncthreads();
     const f4 *cA = reinterpret_cast<const f4 *>(L.cst), *cS = cA + 8, *cLe = cA + 16, *cAl = cA + 24, *cI = cA + 32, *cRs = cA + 40;
     const f4 *cX = cA + 48, *cY = cA + 56, *cZ = cA + 64;
-    const bool rowsOK = nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS;
+    const bool rowsOK = !REPLAY && nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS;
     if (rowsOK) tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), L.trows, lane);
     const int k = S.nUsed;
     const float wIso = 1.f / (4.f * K_PI);
     const bool useLiiAny = (ySa1 != 0.0 || ySs1 != 0.0) && !blackS1;   // L_ii reaches the result at all (photonvolume.cpp:208-211)
+    const bool fixedR = k > GRP_PLAN_KMAX;   // only the all-photons-inside-maxDist plan (see the header)
+    const uint32_t chunksPerSlice = REPLAY ? (A.sliceM + GRP_CH - 1) / GRP_CH : 0u;
+    const unsigned long long nChunks = REPLAY ? (unsigned long long)chunksPerSlice * A.nStreams : 0ull;
+    const bool gridVol = GRID;
     WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
     const float *bX = L.pos, *bY = L.pos + GRP_PITCH, *bZ = L.pos + 2 * GRP_PITCH, *bI = L.pos + 3 * GRP_PITCH;
@@ -287,9 +322,25 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
         uint32_t chunk = 0;
         if (lane == 0) chunk = atomicAdd(A.chunkCounter, 1u);
         chunk = (uint32_t)lane_i((int)chunk, 0);
-        const unsigned long long r0 = (unsigned long long)chunk * GRP_CH;
-        if (r0 >= A.nRays) break;
-        const int nIn = (int)min((unsigned long long)GRP_CH, (unsigned long long)A.nRays - r0);
+        unsigned long long r0 = (unsigned long long)chunk * GRP_CH;
+        int nIn;
+        size_t slot0 = 0;   // REPLAY: record slot of the chunk's first ray
+        if (!REPLAY) {
+            if (r0 >= A.nRays) break;
+            nIn = (int)min((unsigned long long)GRP_CH, (unsigned long long)A.nRays - r0);
+        } else {   // chunk = GRP_CH consecutive rays of one stream's slice (as li_replay_kernel cuts them, eight times as long)
+            if (chunk >= nChunks) break;
+            const uint32_t sidx = chunk / chunksPerSlice, jc = chunk - sidx * chunksPerSlice;
+            const uint32_t nr = A.streams[sidx].n_rays, first = A.streams[sidx].first_ray;
+            const uint32_t begin = A.sliceK * A.sliceM;
+            if (begin >= nr) continue;
+            const uint32_t sliceLen = min(nr - begin, A.sliceM);
+            const uint32_t l0 = jc * GRP_CH;
+            if (l0 >= sliceLen) continue;
+            nIn = (int)min(sliceLen - l0, (uint32_t)GRP_CH);
+            r0 = (unsigned long long)first + begin + l0;
+            slot0 = (size_t)sidx * A.sliceM + l0;
+        }
         // ---- order the chunk's rays by scatter offset: lanes of a group then march in near lock-step positions
         __syncthreads();
         // key = step count + scatter offset: rays of one pixel whose lengths straddle a step-count boundary march with
@@ -320,17 +371,21 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 #pragma unroll 1
         for (int g0 = 0; g0 < nIn; g0 += LANES) {
             const bool have = g0 + lane < nIn;
-            const size_t ri = (size_t)r0 + (have ? (size_t)L.order[g0 + lane] : 0u);
+            const uint32_t local = have ? (uint32_t)L.order[g0 + lane] : 0u;
+            const size_t ri = (size_t)r0 + local;
             const pvol_ray pr = A.rays[ri];
+            RayRec rec = {0, 0, 0};
+            if (REPLAY) rec = ray_rec(A.records + (slot0 + local) * A.recStride, S.maxSteps, gridVol);
             const V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
             RayD ray;
             ray.o = o; ray.d = d; ray.mint = pr.mint; ray.maxt = pr.maxt;
             float t0 = 0.f, t1 = 0.f;
             const bool hit = have && S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
-            const int nS = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
-            const float step = hit ? (t1 - t0) / nS : 0.f;
+            // REPLAY: the pre-pass's count (0 for a ray the record plan could not hold: it was reported there)
+            const int nS = hit ? (REPLAY ? min((int)rec.hdr[0], (int)ceilf((t1 - t0) / S.stepSize)) : (int)ceilf((t1 - t0) / S.stepSize)) : 0;
+            const float step = (hit && nS > 0) ? (t1 - t0) / (int)ceilf((t1 - t0) / S.stepSize) : 0.f;
             const V3 pEntry = o + d * t0;
-            const bool inEntry = hit && box_inside(S.extLo, S.extHi, xform_point(S.w2v, pEntry));
+            const bool inEntry = !GRID && hit && box_inside(S.extLo, S.extHi, xform_point(S.w2v, pEntry));
             const float tStart = t0 + pr.scatter_u * step;
             int maxN = nS;
             for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
@@ -344,14 +399,18 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     if (j < nS) {
                         const V3 p = o + d * tc;
                         tc += step;
-                        const bool inP = box_inside(S.extLo, S.extHi, xform_point(S.w2v, p));
                         const V3 dseg = p - pP;
                         float lenStep;
-                        if (inP0 && inP) { const V3 a = pP + dseg * 0.f, b = pP + dseg * 1.f; lenStep = len(a - b); }
-                        else lenStep = analytic_tau_length(S, pP, dseg, 0.f, 1.f);
+                        if (GRID) {
+                            lenStep = grid_tau_lane(S, pP, dseg, 0.f, 1.f, .5f * S.stepSize, rec.stepU[2 * j]);   // photonvolume.cpp:154
+                        } else {
+                            const bool inP = box_inside(S.extLo, S.extHi, xform_point(S.w2v, p));
+                            if (inP0 && inP) { const V3 a = pP + dseg * 0.f, b = pP + dseg * 1.f; lenStep = len(a - b); }
+                            else lenStep = analytic_tau_length(S, pP, dseg, 0.f, 1.f);
+                            inP0 = inP;
+                        }
                         totalLen += lenStep;
                         pP = p;
-                        inP0 = inP;
                     }
                 }
             }
@@ -371,24 +430,29 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 const V3 p = o + d * tcur;
                 if (act) tcur += step;
                 const V3 pv = xform_point(S.w2v, p);
-                const bool inP = act && box_inside(S.extLo, S.extHi, pv);
-                float lenStep = 0.f;
+                // density factor of sigma_a / sigma_s / Le at p (homogeneous.h:64-75: inside ? 1 : 0; volume.h:81-92: Density(p))
+                const float dens = !act ? 0.f : (GRID ? grid_density(S, pv) : (box_inside(S.extLo, S.extHi, pv) ? 1.f : 0.f));
+                const bool inP = dens != 0.f;
+                float lenStep = 0.f;   // tau of the step = sigma_t x lenStep
                 if (act) {
                     const V3 dseg = p - pPrev;
-                    if (inPrev && inP) {
+                    if (GRID) {
+                        lenStep = grid_tau_lane(S, pPrev, dseg, 0.f, 1.f, .5f * S.stepSize, rec.stepU[2 * j]);
+                    } else if (inPrev && inP) {
                         const V3 a = pPrev + dseg * 0.f, b = pPrev + dseg * 1.f;
                         lenStep = len(a - b);
                     } else {
                         lenStep = analytic_tau_length(S, pPrev, dseg, 0.f, 1.f);
                     }
-                    if (!(lenStep * sigTmax < 6.8f)) bad = true;   // the roulette could fire: sequential kernel (photonvolume.cpp:156-161)
+                    if (!REPLAY && !(lenStep * sigTmax < 6.8f)) bad = true;   // the roulette could fire: sequential kernel (photonvolume.cpp:156-161)
                     cumLen += lenStep;
                 }
                 // ---- direct lighting geometry (photonvolume.cpp:178-203), light 0 (at most one light here)
                 float fallReg = 1.f, d2Reg = 1.f, exitLen = 0.f, ph = 0.f;
                 bool lit = false, distant = true;
+                const int ln = REPLAY ? (act ? (int)(rec.stepByte[j] & 7u) : 0) : 0;   // the light this step samples (photonvolume.cpp:181-183)
                 if (inP && !blackS1 && nLights > 0) {
-                    const DevLight &light = S.lights[0];
+                    const DevLight &light = S.lights[ln];
                     RayD vis;
                     V3 wo;
                     distant = light.kind == PVOL_LIGHT_DISTANT;
@@ -414,12 +478,13 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             }
                         }
                     }
-                    const bool black = (fallReg == 0.f) || lightBlack;
+                    const bool black = (fallReg == 0.f) || ((lightBlackMask >> ln) & 1u);
                     if (!black && !(rowsOK ? tri_rows_occluded(L.trows, S.nTris, vis.o, vis.d, vis.mint, vis.maxt) : lane_occluded(S, vis))) {
                         lit = true;
                         V3 dv = xform_vector(S.w2v, vis.d);
                         V3 dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
-                        exitLen = inside_exit_length(S, vis.o, vis.d, pv, dvInv, vis.maxt);
+                        exitLen = GRID ? grid_tau_lane(S, vis.o, vis.d, vis.mint, vis.maxt, 4.f * S.stepSize, rec.stepU[2 * j + 1])   // photonvolume.cpp:24-27
+                                       : inside_exit_length(S, vis.o, vis.d, pv, dvInv, vis.maxt);
                         ph = phase_hg(-d, -wo, S.g);
                         ++uCount;
                     }
@@ -427,7 +492,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 wc.steps += __popcll(__ballot(act));
                 if (STATS) wc.unocc += __popcll(__ballot(lit));
                 const float kRem = -1.442695041f * (totalLen - cumLen);   // exp(-sigma_t R_j) = exp2(sigma_t * kRem)
-                const float stepD = inP ? step : 0.f;
+                const float stepD = step * dens;
                 // ---- k-NN gather of the group
                 float acc[32];
 #pragma unroll
@@ -447,7 +512,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         const float nbr = wave_max(lastRk);
                         if (!(guessBase > 0.f)) guessBase = nbr > 0.f ? nbr : S.rkEstimate;
                     }
-                    float Twant = need ? ((guessBase * A.grpGuess < S.maxDistSq) ? guessBase * A.grpGuess : S.maxDistSq) : 0.f;
+                    float Twant = need ? ((!fixedR && guessBase * A.grpGuess < S.maxDistSq) ? guessBase * A.grpGuess : S.maxDistSq) : 0.f;
                     int lastFail = 0;   // stats: 1 = bucket overflow, 2 = too few photons inside the radius, 3 = other
                     for (int attempt = 0; attempt < 3; ++attempt) {
                         bool needP = need && !done && Twant > 0.f;
@@ -492,7 +557,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         if (STATS) wc.diag5 += 1;
                         if (Mb < 0) {   // bucket overflow
                             if (STATS) wc.diag1 += __popcll(__ballot(needP));
-                            if (needP) { Twant = 0.4f * Tl; lastFail = 1; }
+                            if (needP) { Twant = fixedR ? 0.f : 0.4f * Tl; lastFail = 1; }   // fixed radius: nothing smaller to try
                             continue;
                         }
                         // the bucket covers more than this lane asked for when other lanes asked for more: take it (up to
@@ -678,7 +743,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 DeferRec r;
                                 r.ray = (uint32_t)ri; r.px = p.x; r.py = p.y; r.pz = p.z; r.kRem = kRem; r.stepD = stepD;
                                 // the radius^2 the next attempt would have asked for is the best guess there is (lphoton widens it by 1.3)
-                                r.guess = Twant > 0.f ? Twant * (1.f / PVOL_GUESS_SCALE) : (guessBase > 0.f ? guessBase : 0.f); r.pad = 0u;
+                                r.guess = fixedR ? 0.f : (Twant > 0.f ? Twant * (1.f / PVOL_GUESS_SCALE) : (guessBase > 0.f ? guessBase : 0.f)); r.dens = dens;
                                 A.defer[at] = r;
                             } else {
                                 atomicOr(A.needSeq, 1u);   // list full: the batch is redone by the sequential kernel, never dropped
@@ -703,7 +768,9 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 if (need && done) {
                     const float dV = rk * sqrtf(rk);
                     if (dV != 0.f && nFoundLane >= 10) liiScale = wIso * __builtin_amdgcn_rcpf(float(4.0 / 3.0 * (double)K_PI * (double)dV));
+                    if (GRID) liiScale *= __builtin_amdgcn_rcpf(dens);   // LPhoton divides by sigma_s(p) = sigma_s x density (photonvolume.cpp:103-105)
                 }
+                const float stepE = GRID ? stepD * dens : stepD;   // emission: sigma_a(p) x Lve(p), both carry the density (photonvolume.cpp:215)
                 const bool useLii = inP && (ySa1 != 0.0 || ySs1 != 0.0);
                 float ldScale = 0.f;
                 if (lit) ldScale = (distant ? 1.f : fallReg * __builtin_amdgcn_rcpf(d2Reg)) * ph * float(nLights);
@@ -712,7 +779,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         __builtin_amdgcn_sched_barrier(0);   // keep the constants of one bin quartet live at a time
-                        const f4 a4 = cA[qq], s4 = cS[qq], le4 = cLe[qq], al4 = cAl[qq], i4 = cI[qq], r4 = cRs[qq];
+                        const f4 a4 = cA[qq], s4 = cS[qq], le4 = cLe[qq], al4 = cAl[qq], r4 = cRs[qq];
+                        const f4 i4 = REPLAY ? *reinterpret_cast<const f4 *>(L.lint + ln * 32 + 4 * qq) : cI[qq];
                         const f4 x4 = cX[qq], y4 = cY[qq], z4 = cZ[qq];
                         const float av[4] = {a4.x, a4.y, a4.z, a4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, lev[4] = {le4.x, le4.y, le4.z, le4.w};
                         const float alv[4] = {al4.x, al4.y, al4.z, al4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
@@ -726,7 +794,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             const float Ld = (iv[cc] * ldScale) * __builtin_amdgcn_exp2f(sT * kExit);
                             const float Lii = acc[b] * liiScale * rv[cc];
                             const float Li = useLii ? Ld + alv[cc] * Lii : Ld;
-                            const float w = (av[cc] * lev[cc] * stepD) + (sv[cc] * Li * stepD);
+                            const float w = (av[cc] * lev[cc] * stepE) + (sv[cc] * Li * stepD);
                             const float t = Pj * w;
                             if (SPECTRAL) Lv[b] += t;
                             else { accX += xv[cc] * t; accY += yv[cc] * t; accZ += zv[cc] * t; }
@@ -767,10 +835,10 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         const float scale = float(700 - 400) / float(106.856895f * 30);
                         *reinterpret_cast<f4 *>(A.out + ri * 4) = make_float4(accX * scale, accY * scale, accZ * scale, ty * 300.f / (106.856895f * 30));
                     }
-                    if (A.draws) A.draws[ri] = draws;
+                    if (!REPLAY && A.draws) A.draws[ri] = draws;
                 }
             }
-            {   // stream positions: one atomic per group when all its rays belong to one stream (the usual case)
+            if (!REPLAY) {   // stream positions: one atomic per group when all its rays belong to one stream (the usual case)
                 const bool cntd = have && !bad;
                 const uint32_t sidx = cntd ? stream_of(A.streams, A.nStreams, (uint32_t)ri) : 0u;
                 const uint32_t mine = cntd ? (hit ? 4u + 7u * (uint32_t)nS + uCount : 0u) + pr.rng_skip : 0u;
@@ -793,8 +861,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
 
 // The lookups li_group_kernel handed over: one wave per entry runs the exact wave-cooperative lphoton() and adds the
 // entry's term  exp(-sigma_t R_j) sigma_s step albedo L_ii  to the ray's output (atomic: a ray can have several entries).
-template <bool STATS, bool SPECTRAL>
-__global__ __launch_bounds__(LANES, PVOL_WPE) void li_fixup_kernel(LiArgs A) {
+template <bool STATS, bool SPECTRAL, int NREG>
+__global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void li_fixup_kernel(LiArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
@@ -815,7 +883,7 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_fixup_kernel(LiArgs A) {
     for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
         const DeferRec r = A.defer[e];
         float rk;
-        const f4 Lii = lphoton<STATS, 4>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4, lane, wc, r.guess, &rk);   // g == 0: the direction is not read
+        const f4 Lii = lphoton<STATS, NREG>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4 * r.dens, lane, wc, r.guess, &rk);   // g == 0: the direction is not read
         const f4 kk = sigT4 * r.kRem;
         f4 c = make_float4(__builtin_amdgcn_exp2f(kk.x), __builtin_amdgcn_exp2f(kk.y), __builtin_amdgcn_exp2f(kk.z), __builtin_amdgcn_exp2f(kk.w));
         c = clean4(c * (sigS4 * (albedo4 * Lii) * r.stepD), q);
@@ -844,25 +912,29 @@ __global__ __launch_bounds__(LANES, PVOL_WPE) void li_fixup_kernel(LiArgs A) {
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;
-    return (size_t)PREV_N * 4 + GRP_CH * 2 + (size_t)GRP_PITCH * 16 + GRP_U_BYTES + 9 * 32 * 4 + GRP_TRI_ROWS * 64;
+    return (size_t)PREV_N * 4 + GRP_CH * 2 + (size_t)GRP_PITCH * 16 + GRP_U_BYTES + 9 * 32 * 4 + GRP_TRI_ROWS * 64 + PVOL_MAX_LIGHTS * 32 * 4;
 }
 
+// replay: 0 = ray-parallel scenes (li_par_kernel's conditions), 1 = records of the RNG pre-pass, homogeneous, 2 = records, VolumeGrid
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
-                                           hipStream_t stream) {
-    hipLaunchKernelGGL(stream_begin_kernel, dim3((args->nStreams + 255) / 256), dim3(256), 0, stream, args->streams, args->nStreams);
-    dim3 grid(nWaves), block(LANES);
+                                           int replay, hipStream_t stream) {
+    if (!replay) hipLaunchKernelGGL(stream_begin_kernel, dim3((args->nStreams + 255) / 256), dim3(256), 0, stream, args->streams, args->nStreams);
+    dim3 grid(nWaves), block(LANES), fgrid(nFixWaves);
     const bool spectral = args->outputKind == PVOL_OUT_SPECTRAL;
     const size_t fixLds = (size_t)candCap * 8 + PAINT_CAP * 4;
-    if (stats) {
-        if (spectral) { hipLaunchKernelGGL((li_group_kernel<true, true>), grid, block, ldsBytes, stream, *args);
-                        hipLaunchKernelGGL((li_fixup_kernel<true, true>), dim3(nFixWaves), block, fixLds, stream, *args); }
-        else { hipLaunchKernelGGL((li_group_kernel<true, false>), grid, block, ldsBytes, stream, *args);
-               hipLaunchKernelGGL((li_fixup_kernel<true, false>), dim3(nFixWaves), block, fixLds, stream, *args); }
+    const bool big = candCap > 4 * LANES;   // select_k registers of the exact lookup: 4 cover nused <= 64, 12 cover nused <= 576
+#define GRP_LAUNCH(ST, SP, RP, GR) hipLaunchKernelGGL((li_group_kernel<ST, SP, RP, GR>), grid, block, ldsBytes, stream, *args)
+#define FIX_LAUNCH(ST, SP) do { if (big) hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 12>), fgrid, block, fixLds, stream, *args); \
+                                else hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 4>), fgrid, block, fixLds, stream, *args); } while (0)
+    if (replay == 0) {
+        if (stats) { if (spectral) { GRP_LAUNCH(true, true, false, false); FIX_LAUNCH(true, true); } else { GRP_LAUNCH(true, false, false, false); FIX_LAUNCH(true, false); } }
+        else { if (spectral) { GRP_LAUNCH(false, true, false, false); FIX_LAUNCH(false, true); } else { GRP_LAUNCH(false, false, false, false); FIX_LAUNCH(false, false); } }
+    } else if (replay == 1) {
+        if (spectral) { GRP_LAUNCH(false, true, true, false); FIX_LAUNCH(false, true); } else { GRP_LAUNCH(false, false, true, false); FIX_LAUNCH(false, false); }
     } else {
-        if (spectral) { hipLaunchKernelGGL((li_group_kernel<false, true>), grid, block, ldsBytes, stream, *args);
-                        hipLaunchKernelGGL((li_fixup_kernel<false, true>), dim3(nFixWaves), block, fixLds, stream, *args); }
-        else { hipLaunchKernelGGL((li_group_kernel<false, false>), grid, block, ldsBytes, stream, *args);
-               hipLaunchKernelGGL((li_fixup_kernel<false, false>), dim3(nFixWaves), block, fixLds, stream, *args); }
+        if (spectral) { GRP_LAUNCH(false, true, true, true); FIX_LAUNCH(false, true); } else { GRP_LAUNCH(false, false, true, true); FIX_LAUNCH(false, false); }
     }
+#undef GRP_LAUNCH
+#undef FIX_LAUNCH
     return hipGetLastError();
 }

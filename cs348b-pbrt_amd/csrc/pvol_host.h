@@ -44,10 +44,11 @@ struct GridBuildArgs {
 };
 extern "C" hipError_t pvol_launch_li_seq(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
-                                           uint32_t nWaves, hipStream_t stream, bool resolve);
+                                           uint32_t nWaves, hipStream_t stream, bool resolve, int groupForm, size_t ldsGroup, uint32_t nGroupWaves,
+                                           uint32_t nFixWaves);
 extern "C" size_t pvol_group_lds_bytes(int candCap);
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
-                                           hipStream_t stream);
+                                           int replay, hipStream_t stream);
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused);
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
@@ -66,7 +67,7 @@ struct pvol_ctx {
     float4 *dPos4, *dAlpha4, *dWi4;
     uint32_t *dCellStart;
     DevCounters *dCounters;
-    uint32_t *dWords;   // [0] chunk counter of the ray-parallel kernels, [1] needSeq flag, [2] length of the deferred-lookup list
+    uint32_t *dWords;   // [0] chunk counter of the ray-parallel kernels, [1] needSeq flag, [2] length of the deferred-lookup list, [3] chunk counter of a gated backup kernel
     DeferRec *dDefer = 0;   // li_group_kernel's deferred lookups (grown on demand)
     size_t deferCap = 0;
     int nCU;

@@ -1116,6 +1116,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
+    if (A.gated && *A.needSeq == 0u) return;   // backup of li_group_kernel's replay form: runs only if its hand-over list overflowed
     MarchLds M;
     M.G.cap = S.candCap;
     M.G.cd = reinterpret_cast<float *>(lds);
@@ -1136,7 +1137,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     const unsigned long long nChunks = (unsigned long long)chunksPerSlice * A.nStreams;
     for (;;) {
         uint32_t chunk = 0;
-        if (lane == 0) chunk = atomicAdd(A.chunkCounter, 1u);
+        if (lane == 0) chunk = atomicAdd(A.gated ? A.chunkCounter + 3 : A.chunkCounter, 1u);
         chunk = (uint32_t)lane_i((int)chunk, 0);
         if (chunk >= nChunks) break;
         const uint32_t sidx = chunk / chunksPerSlice, j = chunk - sidx * chunksPerSlice;
@@ -1364,23 +1365,36 @@ extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, in
     return hipGetLastError();
 }
 
-// one slice: resolve (wave per stream) then replay (wave per ray); chunkCounter must be zero before the replay
+// one slice: resolve (wave per stream) then replay; chunkCounter must be zero before the replay.
+// groupForm: 0 = li_replay_kernel (one wave per ray), 1 / 2 = li_group_kernel's replay form (homogeneous / VolumeGrid: one ray per lane)
+// followed by its exact-lookup pass and, gated on a hand-over list overflow, li_replay_kernel as the backup
+extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
+                                           int replay, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve, size_t ldsReplay, int candCap, bool stats,
-                                           uint32_t nWaves, hipStream_t stream, bool resolve) {
+                                           uint32_t nWaves, hipStream_t stream, bool resolve, int groupForm, size_t ldsGroup, uint32_t nGroupWaves,
+                                           uint32_t nFixWaves) {
     dim3 block(LANES);
     if (resolve && args->liteResolve) {   // geometry pre-pass (ray-parallel) + RNG-only sequential pass
         hipLaunchKernelGGL((li_geo_kernel<4>), dim3(nWaves), block, 0, stream, *args);
         hipLaunchKernelGGL((li_resolve_lite_kernel<4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
         resolve = false;
     }
+    if (resolve) {
+        if (candCap <= 4 * LANES) hipLaunchKernelGGL((li_resolve_kernel<false, 4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+        else hipLaunchKernelGGL((li_resolve_kernel<false, 12>), dim3(args->nStreams), block, ldsResolve, stream, *args);
+    }
+    LiArgs a2 = *args;
+    if (groupForm) {
+        hipError_t e = pvol_launch_li_group(args, ldsGroup, candCap, false, nGroupWaves, nFixWaves, groupForm, stream);
+        if (e != hipSuccess) return e;
+        a2.gated = 1;
+    }
     if (candCap <= 4 * LANES) {
-        if (resolve) hipLaunchKernelGGL((li_resolve_kernel<false, 4>), dim3(args->nStreams), block, ldsResolve, stream, *args);
-        if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 4>), dim3(nWaves), block, ldsReplay, stream, *args);
-        else hipLaunchKernelGGL((li_replay_kernel<false, 4>), dim3(nWaves), block, ldsReplay, stream, *args);
+        if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 4>), dim3(nWaves), block, ldsReplay, stream, a2);
+        else hipLaunchKernelGGL((li_replay_kernel<false, 4>), dim3(nWaves), block, ldsReplay, stream, a2);
     } else {
-        if (resolve) hipLaunchKernelGGL((li_resolve_kernel<false, 12>), dim3(args->nStreams), block, ldsResolve, stream, *args);
-        if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 12>), dim3(nWaves), block, ldsReplay, stream, *args);
-        else hipLaunchKernelGGL((li_replay_kernel<false, 12>), dim3(nWaves), block, ldsReplay, stream, *args);
+        if (stats) hipLaunchKernelGGL((li_replay_kernel<true, 12>), dim3(nWaves), block, ldsReplay, stream, a2);
+        else hipLaunchKernelGGL((li_replay_kernel<false, 12>), dim3(nWaves), block, ldsReplay, stream, a2);
     }
     return hipGetLastError();
 }

@@ -216,3 +216,56 @@ def test_headline_shape_256spp_on_a_million_photon_map(pvol, orc):
         assert st["n_guess_retries"] <= 0.05 * st["n_steps"], st   # the bucket plan, not the exact lookup, is what ran
     finally:
         pv.close()
+
+
+def _grid_scene(n):
+    """volumescene with the synthetic config-4 VolumeGrid at n^3 (the generator of tools/measure_configs.py)."""
+    s = dict(load_scene("volumescene_grid16"))
+    s["vol.dims"] = np.array([n, n, n], np.int32)
+    g = (np.arange(n) + .5) / n
+    zz, yy, xx = np.meshgrid(g, g, g, indexing="ij")
+    rng = np.random.default_rng(348)
+    dens = 0.5 + 0.5 * np.sin(7 * xx) * np.sin(5 * yy) * np.sin(3 * zz) + 0.25 * (rng.random((n, n, n)) - .5)
+    s["vol.density"] = np.clip(dens, 0, 1.5).astype(np.float32).reshape(-1)
+    return s
+
+
+@pytest.mark.parametrize("case", ["grid128", "pinkfloyd_k500", "pinkfloyd_k50"])
+def test_group_replay_form_matches_oracle(pvol, orc, case):
+    """Scenes where drawn values reach the result run as RNG pre-pass + li_group_kernel's REPLAY form (+ the exact-lookup pass):
+    C4's 128^3 VolumeGrid (trilinear density and stepped tau() per lane, recorded offsets), and pinkfloyd's two lights with
+    C3's nused 500 (fixed-radius plan, dense lookups handed to li_fixup_kernel) and with nused 50 (the bucket plan proper)."""
+    if case == "grid128":
+        s = _grid_scene(128)
+        over, n_photons, n_tasks, res, spp, tasks = {}, 200000, 2048, (256, 256), 16, [40, 130, 200]
+    elif case == "pinkfloyd_k500":
+        s = load_scene("pinkfloyd")
+        over, n_photons, n_tasks, res, spp, tasks = {"n_caustic_photons": 0}, 400000, 64, (480, 270), 4, [100, 230, 300, 410]
+    else:
+        s = load_scene("pinkfloyd")
+        over, n_photons, n_tasks, res, spp, tasks = {"n_caustic_photons": 0, "n_used": 50, "max_dist": 0.25}, 400000, 64, (480, 270), 4, [100, 230, 300, 410]
+    pv, p, photons = _dense_map(pvol, s, n_photons, n_tasks, **over)
+    try:
+        assert pv.photon_count() >= n_photons
+        rays, streams = _camera_batch(orc, s, res[0], res[1], spp, 512, tasks)
+        assert len(rays) >= 2000
+        got, gd = pv.li(rays, streams.copy())
+        assert pv.march_kernel_name() == "li_group_kernel"
+        pv.check_errors()
+        o = orc.Oracle(abi.SceneHolder(s), p)
+        o.set_photons(*photons)
+        ref, rd = o.li_batch(rays, streams.copy(), n_threads=8)
+        assert (gd == rd).all()
+        lit = np.linalg.norm(ref[:, :30], axis=1) > 0
+        assert lit.sum() > len(rays) // 8
+        floor = 1e-6 * float(np.abs(ref[:, :30]).max())
+        err = rel_l2(got[:, :30], ref[:, :30], floor=floor)
+        # exact ties for the k-th place aside (see the headline test), every ray is within the bar
+        assert (err > TOL).mean() <= 2e-3 and err.max() <= 2e-3, "rel L2 %.3g at ray %d, %d above 1e-4" % (err.max(), int(err.argmax()), int((err > TOL).sum()))
+        np.testing.assert_allclose(got[:, 30:], ref[:, 30:], rtol=1e-5, atol=1e-7)
+        g_end, o_end = streams.copy(), streams.copy()
+        pv.li(rays, g_end)
+        o.li_batch(rays, o_end)
+        assert (g_end["end_draw"] == o_end["end_draw"]).all()
+    finally:
+        pv.close()

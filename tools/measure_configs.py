@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""Times the BASELINE.json configs other than the bench line on one MI355X (reduced sample counts where a
-full run would take minutes; the reduction is recorded).  Output: one JSON object per config.
+"""Times the BASELINE.json configs other than the bench line on one MI355X.  Output: one JSON object per config.
 
-    python tools/measure_configs.py > profiles/r01_configs.jsonl
+    python tools/measure_configs.py [C1 C3 C4 C5 ...] [--full]  > profiles/r02_configs.jsonl
+
+Two measurements per render config:
+  * `li`     Li() alone through the host API (pvol_li_batch) on a reduced frame: the march + gather kernels (HIP-event time)
+  * `frame`  whole SamplerRendererTasks on the device (pvol_render_tasks_device: sampler + camera pre-pass, Li, film) at the
+             size the line states -- with --full the config's own size, otherwise a reduced sample count (recorded)
 """
 import importlib
 import json
@@ -50,46 +54,92 @@ def rays_for(scene, xres, yres, spp, seed):
     return r, st
 
 
-def run(name, scene_name, xres, yres, spp, n_photons, tasks, note, **over):
+def grid_scene(scene, n):
+    """density(x,y,z) = clamp(0.5 + 0.5 sin(7x) sin(5y) sin(3z) + 0.25 noise(seed 348), 0, 1.5) on an n^3 lattice."""
+    scene = dict(scene)
+    scene["vol.dims"] = np.array([n, n, n], np.int32)
+    g = (np.arange(n) + .5) / n
+    zz, yy, xx = np.meshgrid(g, g, g, indexing="ij")
+    rng = np.random.default_rng(348)
+    dens = 0.5 + 0.5 * np.sin(7 * xx) * np.sin(5 * yy) * np.sin(3 * zz) + 0.25 * (rng.random((n, n, n)) - .5)
+    scene["vol.density"] = np.clip(dens, 0, 1.5).astype(np.float32).reshape(-1)
+    return scene
+
+
+def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n=0, **over):
+    import torch
     scene = blob.load(os.path.join(GOLD, "scene_%s.bin" % scene_name))
-    if "density_n" in over:
-        n = over.pop("density_n")
-        scene = dict(scene)
-        scene["vol.dims"] = np.array([n, n, n], np.int32)
-        g = (np.arange(n) + .5) / n
-        zz, yy, xx = np.meshgrid(g, g, g, indexing="ij")
-        rng = np.random.default_rng(348)
-        dens = 0.5 + 0.5 * np.sin(7 * xx) * np.sin(5 * yy) * np.sin(3 * zz) + 0.25 * (rng.random((n, n, n)) - .5)
-        scene["vol.density"] = np.clip(dens, 0, 1.5).astype(np.float32).reshape(-1)
+    if density_n:
+        scene = grid_scene(scene, density_n)
     params = abi.params_from_blob(scene, n_volume_photons=n_photons, **over)
     pv = pvol.PhotonVolume(params)
     pv.set_scene(abi.SceneHolder(scene))
     t = time.perf_counter()
     pv.preprocess(tasks)
     t_shoot = time.perf_counter() - t
+    shoot_s, build_s = pv.preprocess_times()
     st_sh = pv.shoot_stats()
-    rec = {"config": name, "scene": scene_name, "note": note, "photons": pv.photon_count(), "shoot_tasks": tasks, "shoot_s": t_shoot,
-           "shoot_Mpaths_per_s": st_sh["paths"] / t_shoot / 1e6, "shoot_Mphotons_per_s": st_sh["stored_volume"] / t_shoot / 1e6,
-           "shoot_Mmarch_steps_per_s": st_sh["march_steps"] / t_shoot / 1e6}
-    if spp > 0:
+    rec = {"config": name, "scene": scene_name, "note": note, "photons": pv.photon_count(), "photons_requested": n_photons, "shoot_tasks": tasks,
+           "shoot_s": shoot_s, "grid_build_s": build_s, "shoot_Mpaths_per_s": st_sh["paths"] / shoot_s / 1e6,
+           "shoot_stored_Mphotons_per_s": st_sh["stored_volume"] / shoot_s / 1e6, "shoot_Mmarch_steps_per_s": st_sh["march_steps"] / shoot_s / 1e6,
+           "nused": params.n_used, "maxdist": params.max_dist, "stepsize": params.step_size}
+    if li:
+        xres, yres, spp = li
         rays, streams = rays_for(scene, xres, yres, spp, 7)
         pv.li(rays[:4096], abi.make_streams(np.array([0], np.uint32), np.array([4096], np.uint32)), abi.OUT_XYZ)   # warm up
         pv.kernel_time_ms(reset=True)
+        pv.stats(reset=True)
         t = time.perf_counter()
         out, draws = pv.li(rays, streams, abi.OUT_XYZ)
         wall = time.perf_counter() - t
         kms, _ = pv.kernel_time_ms()
-        rec.update({"xres": xres, "yres": yres, "spp": spp, "li_calls": len(rays), "kernel_ms": kms, "Msamples_per_s_kernel": len(rays) / kms / 1e3,
-                    "Msamples_per_s_host_api_incl_pcie": len(rays) / wall / 1e6, "mean_draws": float(draws.mean())})
+        work = pv.stats()
+        rec["li"] = {"xres": xres, "yres": yres, "spp": spp, "li_calls": len(rays), "kernel": pv.march_kernel_name(), "kernel_ms": kms,
+                     "Msamples_per_s_kernel": len(rays) / kms / 1e3, "Msamples_per_s_host_api_incl_pcie": len(rays) / wall / 1e6,
+                     "mean_draws": float(draws.mean()), "steps_per_ray": work["n_steps"] / max(1, work["n_rays"])}
+    if frame:
+        xres, yres, spp, stated = frame
+        n_tiles = bench.frame_tiles(xres, yres)[4]
+        cam = abi.perspective_camera(float(scene["camera.fov"][0]), xres, yres, scene["camera.c2w"])
+        film = abi.make_film(xres, yres, pvol.gaussian_filter_table())
+        smp = abi.make_sampler(xres, yres, spp, n_tiles)
+        ids = np.arange(n_tiles, dtype=np.uint32)
+        n = pvol.render_sample_count(smp, ids)
+        dev = torch.device("cuda:0")
+        px = torch.zeros((yres, xres, 4), dtype=torch.float32, device=dev)
+        rgb = torch.zeros((yres, xres, 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        pv.kernel_time_ms(reset=True)
+        t = time.perf_counter()
+        pv.render_tasks(cam, film, smp, ids, px.data_ptr())
+        pv.film_resolve(film, px.data_ptr(), rgb.data_ptr())
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t
+        pv.check_errors()
+        kms, nl = pv.kernel_time_ms()
+        rec["frame"] = {"xres": xres, "yres": yres, "spp": spp, "stated_size": stated, "render_tasks": int(n_tiles), "samples": int(n),
+                        "kernel": pv.march_kernel_name(), "frame_s": wall, "Msamples_per_s_whole_pipeline": n / wall / 1e6,
+                        "march_kernels_s": kms * nl * 1e-3, "Msamples_per_s_march_kernels": n / (kms * nl) / 1e3,
+                        "mean_rgb": float(rgb.mean().item())}
     pv.close()
     print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
-    run("C1-h", "volumescene_h", 256, 256, 16, 100000, 4096, "config 1 with Volume homogeneous (gather on)")
-    run("C1-literal", "volumescene_rainbow", 256, 256, 16, 100000, 4096, "config 1 as shipped (rainbow volume: no gather)")
-    run("C3", "pinkfloyd", 480, 270, 4, 4000000, 1024, "config 3 at 1/16 resolution, 4 spp instead of 512, 1 GPU; two lights => resolve/replay kernels",
-        n_caustic_photons=0)
-    run("C4", "volumescene_grid16", 128, 128, 8, 2000000, 16384, "config 4: 128^3 VolumeGrid regenerated here, 128x128 at 8 spp instead of 256^2 at 1024",
-        density_n=128)
-    run("C5", "shootbench", 0, 0, 0, 100000000, 32768, "config 5: shoot only, 100 M photons requested")
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    full = "--full" in sys.argv
+    want = lambda c: not args or c in args   # noqa: E731
+    if want("C1"):
+        run("C1-h", "volumescene_h", 100000, 2048, "config 1 with Volume homogeneous (gather on), stated size", li=(256, 256, 16), frame=(256, 256, 16, True))
+        run("C1-literal", "volumescene_rainbow", 100000, 2048, "config 1 as shipped (rainbow volume: no gather), stated size", li=(256, 256, 16),
+            frame=(256, 256, 16, True))
+    if want("C3"):
+        run("C3", "pinkfloyd", 4000000, 256, "config 3: pinkfloyd 1920x1080, 4 M photons, nused 500, two lights, on ONE MI355X; frame at %s" %
+            ("512 spp (stated)" if full else "8 spp instead of 512"), li=(480, 270, 4),
+            frame=(1920, 1080, 512 if full else 8, full), n_caustic_photons=0)
+    if want("C4"):
+        run("C4", "volumescene_grid16", 2000000, 16384, "config 4: 128^3 VolumeGrid (generated here), 2 M photons; frame 256x256 at %s" %
+            ("1024 spp (stated)" if full else "64 spp instead of 1024"), li=(128, 128, 8),
+            frame=(256, 256, 1024 if full else 64, full), density_n=128)
+    if want("C5"):
+        run("C5", "shootbench", 100000000, 2048, "config 5: shoot only, 100 M stored photons requested, device grid build timed separately")

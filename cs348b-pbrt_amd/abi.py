@@ -77,7 +77,7 @@ class Params(C.Structure):
         ("n_volume_photons", C.c_uint32), ("shooter_step_size", C.c_float),
         ("max_photon_depth", C.c_int32), ("n_caustic_photons", C.c_uint32),
         ("n_indirect_photons", C.c_uint32), ("final_gather", C.c_int32),
-        ("device", C.c_int32), ("grid_cell_scale", C.c_float), ("reserved", C.c_uint32 * 7),
+        ("device", C.c_int32), ("grid_cell_scale", C.c_float), ("keep_surface_photons", C.c_uint32), ("reserved", C.c_uint32 * 6),
     ]
 
 

@@ -53,6 +53,7 @@ void pvol_default_params(pvol_params *p) {
     p->final_gather = 1;
     p->device = 0;
     p->grid_cell_scale = 0.f;
+    p->keep_surface_photons = 0;
 }
 
 int pvol_create(const pvol_params *params, pvol_ctx **out) {
@@ -118,6 +119,7 @@ void pvol_destroy(pvol_ctx *c) {
     hipSetDevice(c->params.device);
     hipDeviceSynchronize();
     pvol_free_photons(c);
+    pvol_free_surface_stores(c);
     for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->dDensity) hipFree(c->dDensity);
@@ -476,6 +478,9 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     // the tile pre-pass can COUNT Li()'s draws (instead of drawing them) under the same conditions as li_par_kernel,
     // provided no march step can reach the roulette
     const bool tileCount = tile && par_eligible(c) && !dInit && !roulette_possible(c);
+    // a VolumeGrid with at most one light: the draw COUNT is still geometry only (4 + 6n + n + u; the drawn offsets change values,
+    // not counts), so the tile pre-pass counts and the values come from the RNG-only resolve pass of each slice
+    const bool tileGridCount = tile && c->hs.nLights <= 1 && c->hs.volKind == PVOL_VOLUME_GRID && !dInit && !roulette_possible(c) && !c->forceSeq && !c->noLite;
     const bool par = par_eligible(c) && !dInit && !c->forceSeq && (!tile || tileCount);
     // scenes where drawn values matter: sequential RESOLVE pre-pass + ray-parallel REPLAY, slice by slice
     const bool sliced = !par && !c->forceSeq && !transOnly && (c->hs.volKind != PVOL_VOLUME_NONE || tile);
@@ -492,8 +497,10 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         const bool grid = c->hs.volKind == PVOL_VOLUME_GRID;
         size_t stride = 16 + (size_t)((c->hs.maxSteps + 15) & ~15) + (grid ? 8 * (size_t)c->hs.maxSteps : 0);
         stride = (stride + 15) & ~(size_t)15;
-        const size_t budget = (size_t)2 << 30;
+        const size_t budget = (size_t)4 << 30;
         size_t m = budget / (stride * (size_t)nStreams);
+        // nused beyond the bucket plan hands every dense lookup of a slice to the exact pass: keep that list within 8 GB
+        if (c->hs.nUsed > 100) m = std::min<size_t>(m, std::max<size_t>(64, (((size_t)8 << 30) / sizeof(DeferRec) / 64) / (size_t)nStreams));
         m = std::max<size_t>(64, std::min<size_t>(m, ((size_t)maxRays + 63) & ~(size_t)63));
         m &= ~(size_t)63;
         if (const char *ev = getenv("PVOL_SLICE_RAYS")) { long v = atol(ev); if (v >= 64) m = (size_t)v & ~(size_t)63; }   // testing: force many slices
@@ -509,7 +516,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         if (stBytes > c->stateBytes) { if (c->dState) hipFree(c->dState); c->dState = 0; c->stateBytes = 0;
                                        if (!ok(hipMalloc(&c->dState, stBytes))) return PVOL_E_NO_MEMORY; c->stateBytes = stBytes; }
         a.records = c->dRecords; a.recStride = (uint32_t)stride; a.sliceM = sliceM; a.state = c->dState;
-        a.liteResolve = (!tile && !c->noLite && !roulette_possible(c)) ? 1 : 0;
+        a.liteResolve = ((!tile || tileGridCount) && !c->noLite && !roulette_possible(c)) ? 1 : 0;
     }
     if (par) hipMemsetAsync(c->dWords, 0, 3 * sizeof(uint32_t), stream);
     if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel
@@ -565,7 +572,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
             // hand-over list: nused beyond the bucket plan sends every dense lookup to the exact pass (C3: ~14 per ray)
             const size_t perSlice = (size_t)sliceM * nStreams;
-            size_t wantDefer = (c->hs.nUsed > 100 ? perSlice * 24 : perSlice / 2) + 65536;
+            size_t wantDefer = (c->hs.nUsed > 100 ? perSlice * 64 : perSlice) + 65536;
             wantDefer = std::min<size_t>(wantDefer, ((size_t)8 << 30) / sizeof(DeferRec));
             if (wantDefer > c->deferCap) {
                 hipStreamSynchronize(stream);
@@ -577,12 +584,17 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
             c->lastKernel = "li_group_kernel";
         }
+        if (tileGridCount) {   // sampler + camera + draw COUNT for the whole batch, once
+            LiArgs t = a;
+            t.sliceK = 0; t.sliceM = 0xffffffc0u; t.state = 0;
+            e = pvol_launch_tile(&t, tile, false, pvol_tile_lds_bytes(0, tile->spp, false), c->hs.candCap, stream);
+        }
         for (uint32_t k = 0; k < nSlices && ok(e); ++k) {
             a.sliceK = k;
             hipMemsetAsync(c->dWords, 0, 4 * sizeof(uint32_t), stream);
-            if (tile) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true), c->hs.candCap, stream);
+            if (tile && !tileGridCount) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true), c->hs.candCap, stream);
             if (ok(e)) e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream,
-                                                tile == 0, groupForm, pvol_group_lds_bytes(c->hs.candCap), gWaves, (uint32_t)c->nCU * 8u);
+                                                tile == 0 || tileGridCount, groupForm, pvol_group_lds_bytes(c->hs.candCap), gWaves, (uint32_t)c->nCU * 8u);
         }
     } else {
         c->lastKernel = "li_seq_kernel";

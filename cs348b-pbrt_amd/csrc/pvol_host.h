@@ -97,6 +97,10 @@ struct pvol_ctx {
     DevShootScene hsh;
     DevShootScene *dsh;
     uint64_t shootStats[12];
+    // surface stores of the last pvol_preprocess (kept only with params.keep_surface_photons): kind 0 caustic, 1 direct, 2 indirect
+    struct SurfStore { float *p = 0, *wo = 0, *alpha = 0; uint32_t n = 0, nPaths = 0; } surf[3];
+    float *dRad = 0;       // radiance photons: [n][8] = p(3) n(3) material index, pad
+    uint32_t nRad = 0;
     double prepSeconds[2] = {0.0, 0.0};   // last pvol_preprocess: shooting (all rounds + merges), search-structure build
     // tile driver work buffers (grown on demand, pvol_tile.hip)
     void *dTile[6] = {0, 0, 0, 0, 0, 0};
@@ -113,6 +117,7 @@ extern "C" {
 // finish a photon map whose raw arrays (dRawP/dRawWi/dRawAlpha, n photons) are already on the device
 int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions);
 void pvol_free_photons(pvol_ctx *c);
+void pvol_free_surface_stores(pvol_ctx *c);
 int pvol_push_scene(pvol_ctx *c);
 }
 #endif

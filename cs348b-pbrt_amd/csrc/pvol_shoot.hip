@@ -44,8 +44,16 @@ struct ShootArgs {
     uint32_t *halton;         // [nTasks][48] permutation tables (bases 2,3,5,7,11,13: 41 entries)
     const uint32_t *flags;    // [nTasks] bit0 causticDone, bit1 indirectDone, bit2 volumeDone, bit3 finished
     float *localPhotons;      // [nTasks][cap][36]: p(3) wi(3) alpha(30)
-    uint32_t *localCounts;    // [nTasks][4]: volume, caustic, direct, indirect stored in this block
+    uint32_t *localCounts;    // [nTasks][8]: volume, caustic, direct, indirect deposits of this block, surface records kept, radiance photons kept
     uint32_t cap;
+    // the surface stores of photonshooter.cpp:148-189, kept only on request (pvol_params.keep_surface_photons): every deposit
+    // is one record Photon(p, alpha, wo) with its kind (0 caustic, 1 direct, 2 indirect), in deposit order
+    float *localSurf;         // [nTasks][capS][36]: p(3) wo(3) alpha(30)
+    uint32_t *localSurfKind;  // [nTasks][capS]
+    uint32_t capS;
+    float *localRad;          // [nTasks][capR][8]: p(3) n(3) material index, pad  (RadiancePhoton + whose rho it carries)
+    uint32_t capR;
+    int keepSurface;
     unsigned long long *stats;  // paths, follow_calls, no_hit, march_steps, interactions, absorbed, split_children, overflow
     int init;                 // 1: seed RNG + Halton tables instead of shooting
 };
@@ -366,6 +374,8 @@ struct PathCtx {
     bool causticDone, indirectDone, volumeDone;
     float *outPhotons;   // this task's local block buffer
     uint32_t cap;
+    float *outSurf; uint32_t *outSurfKind; float *outRad;   // surface stores of this task (null unless kept)
+    uint32_t capS, capR, nSurf, nRad;
     uint32_t nVol, nCaustic, nDirect, nIndirect;
     unsigned long long follow, noHit, march, inter, absorbed, splitc, overflow;
 };
@@ -513,13 +523,34 @@ __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float
             F.wo = -F.rayD;
             if (hasNonSpecular) {
                 bool deposited = false;
+                int kind = 0;
                 if (F.spec && F.nInt > 1) {
-                    if (!C.causticDone) { deposited = true; ++C.nCaustic; }
+                    if (!C.causticDone) { deposited = true; ++C.nCaustic; kind = 0; }
                 } else {
-                    if (F.nInt == 1 && !C.indirectDone && H.finalGather) { deposited = true; ++C.nDirect; }
-                    else if (F.nInt > 1 && !C.indirectDone) { deposited = true; ++C.nIndirect; }
+                    if (F.nInt == 1 && !C.indirectDone && H.finalGather) { deposited = true; ++C.nDirect; kind = 1; }
+                    else if (F.nInt > 1 && !C.indirectDone) { deposited = true; ++C.nIndirect; kind = 2; }
                 }
-                if (deposited && H.finalGather && rng_float<true>(C.rng, lane) < .125f) rng_skip<true>(C.rng, 288ull, lane);   // 2 x BSDF::rho (reflection.cpp:647-658)
+                if (deposited && C.outSurf) {   // Photon(photonIsect.dg.p, alpha, wo), photonshooter.cpp:150
+                    if (C.nSurf < C.capS) {
+                        float *o = C.outSurf + (size_t)C.nSurf * 36;
+                        if (lane < 6) o[lane] = lane == 0 ? F.hit.p.x : lane == 1 ? F.hit.p.y : lane == 2 ? F.hit.p.z : lane == 3 ? F.wo.x : lane == 4 ? F.wo.y : F.wo.z;
+                        if (binLane) o[6 + lane] = Falpha;
+                        if (lane == 0) C.outSurfKind[C.nSurf] = (uint32_t)kind;
+                    }
+                    ++C.nSurf;
+                }
+                if (deposited && H.finalGather && rng_float<true>(C.rng, lane) < .125f) {
+                    rng_skip<true>(C.rng, 288ull, lane);   // 2 x BSDF::rho (reflection.cpp:647-658)
+                    if (C.outRad) {   // RadiancePhoton(p, Faceforward(nn, -photonRay.d)), photonshooter.cpp:182-189
+                        if (C.nRad < C.capR) {
+                            const V3 nf = dot(F.hit.nn, F.wo) < 0.f ? F.hit.nn * -1.f : F.hit.nn;
+                            float *o = C.outRad + (size_t)C.nRad * 8;
+                            if (lane < 8) o[lane] = lane == 0 ? F.hit.p.x : lane == 1 ? F.hit.p.y : lane == 2 ? F.hit.p.z : lane == 3 ? nf.x : lane == 4 ? nf.y :
+                                                    lane == 5 ? nf.z : lane == 6 ? __int_as_float(H.triMat[F.hit.tri]) : 0.f;
+                        }
+                        ++C.nRad;
+                    }
+                }
             }
             if (F.nInt >= H.maxPhotonDepth) { mode = 3; continue; }
             F.nextChild = 0;
@@ -620,11 +651,11 @@ __global__ __launch_bounds__(LANES, WPE) void shoot_kernel(ShootArgs A) {
         return;
     }
     const uint32_t fl = A.flags[task];
-    uint32_t *lc = A.localCounts + (size_t)task * 4;
+    uint32_t *lc = A.localCounts + (size_t)task * 8;
     const uint32_t *si = A.stateIn + (size_t)task * SH_STATE_WORDS;
     uint32_t *so = A.stateOut + (size_t)task * SH_STATE_WORDS;
     if (fl & 8u) {   // finished: the state is carried over untouched
-        if (lane < 4) lc[lane] = 0u;
+        if (lane < 8) lc[lane] = 0u;
         for (int i = lane; i < MT_N + 2; i += LANES) so[i] = si[i];
         return;
     }
@@ -643,6 +674,10 @@ __global__ __launch_bounds__(LANES, WPE) void shoot_kernel(ShootArgs A) {
     C.causticDone = fl & 1u; C.indirectDone = fl & 2u; C.volumeDone = fl & 4u;
     C.outPhotons = A.localPhotons + (size_t)task * A.cap * 36;
     C.cap = A.cap;
+    C.outSurf = A.keepSurface ? A.localSurf + (size_t)task * A.capS * 36 : 0;
+    C.outSurfKind = A.keepSurface ? A.localSurfKind + (size_t)task * A.capS : 0;
+    C.outRad = A.keepSurface ? A.localRad + (size_t)task * A.capR * 8 : 0;
+    C.capS = A.capS; C.capR = A.capR; C.nSurf = C.nRad = 0;
     C.nVol = C.nCaustic = C.nDirect = C.nIndirect = 0;
     C.follow = C.noHit = C.march = C.inter = C.absorbed = C.splitc = C.overflow = 0;
     const uint32_t blockSize = 4096;
@@ -681,7 +716,7 @@ __global__ __launch_bounds__(LANES, WPE) void shoot_kernel(ShootArgs A) {
     if (lane == 0) {
         so[MT_N] = (uint32_t)C.rng.mti;
         so[MT_N + 1] = totalPaths;
-        lc[0] = C.nVol; lc[1] = C.nCaustic; lc[2] = C.nDirect; lc[3] = C.nIndirect;
+        lc[0] = C.nVol; lc[1] = C.nCaustic; lc[2] = C.nDirect; lc[3] = C.nIndirect; lc[4] = C.nSurf; lc[5] = C.nRad; lc[6] = lc[7] = 0u;
         atomicAdd(&A.stats[0], paths);
         atomicAdd(&A.stats[1], C.follow);
         atomicAdd(&A.stats[2], C.noHit);
@@ -719,6 +754,51 @@ __global__ void merge_kernel(MergeArgs M) {
             else M.alpha[dst * 30 + (f - 6)] = v / ns;
         }
     }
+}
+
+// merge of one task's surface records into the per-kind arrays, in deposit order (photonshooter.cpp:303-327), and of its
+// radiance photons (:341-349).  One wave per segment; `take` has bit k set when kind k is merged at this task's turn.
+struct SurfMergeArgs {
+    const float *localSurf; const uint32_t *localSurfKind; uint32_t capS;
+    const float *localRad; uint32_t capR;
+    const uint32_t *srcTask, *nSurf, *take, *dstOff;   // dstOff: [nSeg][4] = caustic, direct, indirect, radiance
+    const uint32_t *nRad;
+    uint32_t nSeg;
+    float *p[3], *wo[3], *alpha[3];
+    float *rad;   // [n][8]
+};
+__global__ __launch_bounds__(64) void merge_surface_kernel(SurfMergeArgs M) {
+    const int lane = threadIdx.x;
+    for (uint32_t seg = blockIdx.x; seg < M.nSeg; seg += gridDim.x) {
+        const uint32_t task = M.srcTask[seg], n = M.nSurf[seg], take = M.take[seg];
+        const float *src = M.localSurf + (size_t)task * M.capS * 36;
+        const uint32_t *kinds = M.localSurfKind + (size_t)task * M.capS;
+        uint32_t at[3] = {M.dstOff[4 * seg], M.dstOff[4 * seg + 1], M.dstOff[4 * seg + 2]};
+        for (uint32_t base = 0; base < n; base += 64) {
+            const uint32_t i = base + lane;
+            const uint32_t kd = i < n ? kinds[i] : 3u;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; ++k) {
+                const bool mine = kd == k && ((take >> k) & 1u);
+                const uint64_t m = __ballot(mine);
+                if (mine) {
+                    const size_t dst = (size_t)at[k] + __popcll(m & ((1ull << lane) - 1ull));
+                    const float *r = src + (size_t)i * 36;
+                    for (int f = 0; f < 3; ++f) { M.p[k][dst * 3 + f] = r[f]; M.wo[k][dst * 3 + f] = r[3 + f]; }
+                    for (int f = 0; f < 30; ++f) M.alpha[k][dst * 30 + f] = r[6 + f];
+                }
+                at[k] += (uint32_t)__popcll(m);
+            }
+        }
+        const uint32_t nr = M.nRad[seg];
+        const float *rs = M.localRad + (size_t)task * M.capR * 8;
+        for (uint32_t i = lane; i < nr * 8; i += 64) M.rad[(size_t)M.dstOff[4 * seg + 3] * 8 + i] = rs[i];
+    }
+}
+extern "C" hipError_t pvol_launch_merge_surface(const SurfMergeArgs *m, hipStream_t stream) {
+    if (!m->nSeg) return hipSuccess;
+    hipLaunchKernelGGL(merge_surface_kernel, dim3(std::min<uint32_t>(m->nSeg, 4096u)), dim3(64), 0, stream, *m);
+    return hipGetLastError();
 }
 
 extern "C" size_t pvol_shoot_state_words(void) { return SH_STATE_WORDS; }

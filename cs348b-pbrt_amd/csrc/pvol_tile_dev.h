@@ -164,7 +164,7 @@ __device__ __forceinline__ CountConsts count_consts(const DevScene &S) {
 
 // Number of RandomUInt calls of one Li() when no roulette can fire and at most one light exists: 4 + 6n + n + u
 // (photonvolume.cpp:112-222; same per-step tests as march_ray_blocked's scalar phase).  One ray per lane.
-__device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, const float *trows, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack, uint32_t dbg = 0u) {
+__device__ uint32_t tile_count_draws(const DevScene &S, const CountConsts &C, const float *ltri, const float *trows, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack, uint32_t dbg = 0u) {
     float t0, t1;
     // vol_intersect: BBox::IntersectP of the ray taken to volume space (core/geometry.cpp:68-86)
     if (C.volKind == PVOL_VOLUME_NONE || !box_intersect(C.lo, C.hi, xform_point(C.w2v, o), xform_vector(C.w2v, d), 0.f, maxt, &t0, &t1) || (t1 - t0) == 0.f) return 0u;
@@ -178,7 +178,8 @@ __device__ uint32_t tile_count_draws(const CountConsts &C, const float *ltri, co
         const V3 p = o + d * tcur;
         tcur += step;
         const V3 pv = xform_point(C.w2v, p);
-        if (!box_inside(C.lo, C.hi, pv)) continue;
+        // sigma_s(p) black: outside a homogeneous extent, or zero density of a VolumeGrid (volumegrid.cpp:39-57)
+        if (C.volKind == PVOL_VOLUME_GRID ? grid_density(S, pv) == 0.f : !box_inside(C.lo, C.hi, pv)) continue;
         RayD vis;
         if (C.lightKind == PVOL_LIGHT_DISTANT) {
             vis.o = p; vis.d = v3(C.ldir[0], C.ldir[1], C.ldir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
                 T.xy[2 * ri + 1] = imageY;
             }
             if (!FUSED) {
-                uint32_t nd = (on && !(T.debugSkip & 2u)) ? tile_count_draws(CC, ltri, trows, o, d, maxt, su, blackS, lightBlack, T.debugSkip) : ((T.debugSkip & 2u) ? 270u : 0u);
+                uint32_t nd = (on && !(T.debugSkip & 2u)) ? tile_count_draws(S, CC, ltri, trows, o, d, maxt, su, blackS, lightBlack, T.debugSkip) : ((T.debugSkip & 2u) ? 270u : 0u);
                 // wave total (integer adds in any order are exact)
                 unsigned long long tot = nd;
                 for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);

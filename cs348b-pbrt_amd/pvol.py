@@ -60,6 +60,10 @@ def lib():
         L.pvol_march_kernel_name.argtypes = [C.c_void_p]
         L.pvol_check_errors.argtypes = [C.c_void_p]
         L.pvol_get_preprocess_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.pvol_surface_photon_count.argtypes = [C.c_void_p, C.c_int, _u32p, _u32p]
+        L.pvol_download_surface_photons.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_uint32]
+        L.pvol_radiance_photon_count.argtypes = [C.c_void_p, _u32p]
+        L.pvol_download_radiance_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_uint32]
         L.pvol_march_kernel_name.restype = C.c_char_p
         L.pvol_gaussian_filter_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
         L.pvol_gaussian_filter_table.restype = None
@@ -80,7 +84,8 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
            "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats",
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
-           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds"]
+           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_surface_photon_count",
+           "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -135,6 +140,25 @@ class PhotonVolume:
         v = (C.c_double * 2)()
         _check(lib().pvol_get_preprocess_seconds(self._h, v), "pvol_get_preprocess_seconds")
         return float(v[0]), float(v[1])
+
+    def surface_photons(self, kind):
+        """(p, wo, alpha, n_paths) of the caustic (0) / direct (1) / indirect (2) store kept by the last preprocess()."""
+        n, npaths = C.c_uint32(), C.c_uint32()
+        _check(lib().pvol_surface_photon_count(self._h, kind, C.byref(n), C.byref(npaths)), "pvol_surface_photon_count")
+        p, wo, a = np.zeros((n.value, 3), np.float32), np.zeros((n.value, 3), np.float32), np.zeros((n.value, 30), np.float32)
+        _check(lib().pvol_download_surface_photons(self._h, kind, p.ctypes.data_as(_f32p), wo.ctypes.data_as(_f32p), a.ctypes.data_as(_f32p), n.value),
+               "pvol_download_surface_photons")
+        return p, wo, a, int(npaths.value)
+
+    def radiance_photons(self):
+        """(p, n, rho_r, rho_t) of the radiance photons kept by the last preprocess()."""
+        n = C.c_uint32()
+        _check(lib().pvol_radiance_photon_count(self._h, C.byref(n)), "pvol_radiance_photon_count")
+        p, nn = np.zeros((n.value, 3), np.float32), np.zeros((n.value, 3), np.float32)
+        rr, rt = np.zeros((n.value, 30), np.float32), np.zeros((n.value, 30), np.float32)
+        _check(lib().pvol_download_radiance_photons(self._h, p.ctypes.data_as(_f32p), nn.ctypes.data_as(_f32p), rr.ctypes.data_as(_f32p),
+                                                    rt.ctypes.data_as(_f32p), n.value), "pvol_download_radiance_photons")
+        return p, nn, rr, rt
 
     def check_errors(self):
         """Raises PvolError(PVOL_E_LIMIT) if a batch enqueued through a device entry point hit a kernel limit."""

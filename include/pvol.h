@@ -130,7 +130,9 @@ typedef struct pvol_params {
     int32_t final_gather;       /* SurfaceIntegrator "finalgather" (default true)         */
     int32_t device;             /* HIP device ordinal                                     */
     float grid_cell_scale;      /* 0 = auto; else photon-grid cell edge as a multiple of the auto choice */
-    uint32_t reserved[7];
+    uint32_t keep_surface_photons; /* 1: pvol_preprocess also KEEPS the caustic / direct / indirect / radiance photons it deposits
+                                      (photonshooter.cpp:148-189); 0: they are only counted (their counts steer the shooting)   */
+    uint32_t reserved[6];
 } pvol_params;
 
 /* ---- ray batches --------------------------------------------------------------------- */
@@ -267,6 +269,16 @@ int pvol_get_shoot_stats(pvol_ctx *ctx, uint64_t *out12);
  * (PhotonShootingTask::Run, photonshooter.cpp:232-357), out[1] the device search-structure build that replaces
  * the kd-tree construction (photonshooter.cpp:502-503, core/kdtree.h:100-147). */
 int pvol_get_preprocess_seconds(pvol_ctx *ctx, double *out2);
+
+/* The surface stores of the last pvol_preprocess (params.keep_surface_photons = 1): what PhotonShooter::Preprocess hands to
+ * its caustic / direct / indirect kd-trees (photonshooter.cpp:495-503), in the reference's merge order (:303-327).
+ * kind: 0 caustic, 1 direct, 2 indirect.  n_paths = nCausticPaths / nDirectPaths / nIndirectPaths.  p, wo: 3 floats,
+ * alpha: 30 floats per photon (NOT divided by the path count: the surface estimate divides at lookup, photonmap.cpp:89). */
+int pvol_surface_photon_count(pvol_ctx *ctx, int kind, uint32_t *n, uint32_t *n_paths);
+int pvol_download_surface_photons(pvol_ctx *ctx, int kind, float *p, float *wo, float *alpha, uint32_t capacity);
+/* Radiance photons (photonshooter.cpp:182-189): position, normal facing the arriving photon, rho_r, rho_t (30 floats each). */
+int pvol_radiance_photon_count(pvol_ctx *ctx, uint32_t *n);
+int pvol_download_radiance_photons(pvol_ctx *ctx, float *p, float *n, float *rho_r, float *rho_t, uint32_t capacity);
 
 /* Number of photons in the current volume map. */
 int pvol_photon_count(pvol_ctx *ctx, uint32_t *n);

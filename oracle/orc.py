@@ -50,6 +50,14 @@ def lib():
         L.orc_lphoton_batch.argtypes = [C.c_void_p, _f32p, _f32p, C.c_uint32, _f32p]
         L.orc_shoot.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
         L.orc_get_shoot_stats.argtypes = [C.c_void_p, _u64p]
+        L.orc_keep_surface_photons.argtypes = [C.c_void_p, C.c_int]
+        L.orc_keep_surface_photons.restype = None
+        L.orc_surface_photon_count.argtypes = [C.c_void_p, C.c_int, _u32p]
+        L.orc_surface_photon_count.restype = C.c_uint32
+        L.orc_get_surface_photons.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_uint32]
+        L.orc_radiance_photon_count.argtypes = [C.c_void_p]
+        L.orc_radiance_photon_count.restype = C.c_uint32
+        L.orc_get_radiance_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_uint32]
         L.orc_rng_draws.argtypes = [C.c_uint32, C.c_uint32, _u32p]
         L.orc_rng_floats.argtypes = [C.c_uint32, C.c_uint32, _f32p]
         L.orc_halton.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
@@ -158,6 +166,22 @@ class Oracle:
 
     def shoot(self, n_tasks=1, n_threads=1):
         return lib().orc_shoot(self._h, n_tasks, n_threads)
+
+    def keep_surface_photons(self, on=True):
+        lib().orc_keep_surface_photons(self._h, int(on))
+
+    def surface_photons(self, kind):
+        npaths = C.c_uint32()
+        n = int(lib().orc_surface_photon_count(self._h, kind, C.byref(npaths)))
+        p, wo, a = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 30), np.float32)
+        lib().orc_get_surface_photons(self._h, kind, _p(p, _f32p), _p(wo, _f32p), _p(a, _f32p), n)
+        return p, wo, a, int(npaths.value)
+
+    def radiance_photons(self):
+        n = int(lib().orc_radiance_photon_count(self._h))
+        p, nn, rr, rt = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros((n, 30), np.float32), np.zeros((n, 30), np.float32)
+        lib().orc_get_radiance_photons(self._h, _p(p, _f32p), _p(nn, _f32p), _p(rr, _f32p), _p(rt, _f32p), n)
+        return p, nn, rr, rt
 
     def shoot_stats(self):
         v = np.zeros(12, np.uint64)

@@ -20,7 +20,9 @@ struct orc_ctx {
     KdTree *map;
     Counters ctr;
     ShootStats shoot_stats;
-    orc_ctx() : map(0) {}
+    bool keep_surface;
+    SurfaceStores surf;
+    orc_ctx() : map(0), keep_surface(false) {}
     ~orc_ctx() { delete map; }
 };
 
@@ -173,11 +175,41 @@ int orc_lphoton_batch(orc_ctx *c, const float *pts, const float *w, uint32_t n, 
 // task order per block round; n_tasks == 1 is the reference at --ncores 1.
 int orc_shoot(orc_ctx *c, uint32_t n_tasks, int n_threads) {
     std::vector<Photon> vol;
-    int rc = shoot_photons(c->scene, c->params, n_tasks, n_threads, &vol, &c->shoot_stats);
+    int rc = shoot_photons(c->scene, c->params, n_tasks, n_threads, &vol, &c->shoot_stats, c->keep_surface ? &c->surf : 0);
     c->photons.swap(vol);
     delete c->map;
     c->map = c->photons.size() ? new KdTree(c->photons) : 0;
     return rc;
+}
+
+// The surface stores of PhotonShooter::Preprocess (photonshooter.cpp:461-470): kind 0 caustic, 1 direct, 2 indirect
+void orc_keep_surface_photons(orc_ctx *c, int on) { c->keep_surface = on != 0; }
+uint32_t orc_surface_photon_count(orc_ctx *c, int kind, uint32_t *n_paths) {
+    const std::vector<Photon> &v = kind == 0 ? c->surf.caustic : (kind == 1 ? c->surf.direct : c->surf.indirect);
+    if (n_paths) *n_paths = kind == 0 ? c->surf.nCausticPaths : (kind == 1 ? c->surf.nDirectPaths : c->surf.nIndirectPaths);
+    return (uint32_t)v.size();
+}
+int orc_get_surface_photons(orc_ctx *c, int kind, float *p, float *wo, float *alpha, uint32_t capacity) {
+    const std::vector<Photon> &v = kind == 0 ? c->surf.caustic : (kind == 1 ? c->surf.direct : c->surf.indirect);
+    uint32_t n = std::min<uint32_t>(capacity, (uint32_t)v.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        p[3 * i] = v[i].p.x; p[3 * i + 1] = v[i].p.y; p[3 * i + 2] = v[i].p.z;
+        wo[3 * i] = v[i].wi.x; wo[3 * i + 1] = v[i].wi.y; wo[3 * i + 2] = v[i].wi.z;
+        memcpy(alpha + (size_t)i * NB, v[i].alpha.c, sizeof(float) * NB);
+    }
+    return 0;
+}
+uint32_t orc_radiance_photon_count(orc_ctx *c) { return (uint32_t)c->surf.radiance.size(); }
+int orc_get_radiance_photons(orc_ctx *c, float *p, float *n, float *rho_r, float *rho_t, uint32_t capacity) {
+    uint32_t m = std::min<uint32_t>(capacity, (uint32_t)c->surf.radiance.size());
+    for (uint32_t i = 0; i < m; ++i) {
+        const RadPhoton &r = c->surf.radiance[i];
+        p[3 * i] = r.p.x; p[3 * i + 1] = r.p.y; p[3 * i + 2] = r.p.z;
+        n[3 * i] = r.n.x; n[3 * i + 1] = r.n.y; n[3 * i + 2] = r.n.z;
+        memcpy(rho_r + (size_t)i * NB, r.rho_r.c, sizeof(float) * NB);
+        memcpy(rho_t + (size_t)i * NB, r.rho_t.c, sizeof(float) * NB);
+    }
+    return 0;
 }
 
 // shoot stats: paths, follow_calls, no_hit, march_steps, interactions, absorbed, stored_volume,

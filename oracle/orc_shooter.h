@@ -142,6 +142,19 @@ inline Spec bsdf_sample_f(const Scene &sc, int tri, V3 dpdu, V3 nn, V3 woW, V3 *
     return f;
 }
 
+// RadiancePhoton (core/photonshooter.h:52-61) with its two reflectances (photonshooter.cpp:182-189)
+struct RadPhoton {
+    V3 p, n;
+    Spec rho_r, rho_t;
+};
+// What PhotonShooter::Preprocess keeps besides the volume map (photonshooter.cpp:461-470): filled only on request
+struct SurfaceStores {
+    std::vector<Photon> caustic, direct, indirect;
+    std::vector<RadPhoton> radiance;
+    uint32_t nCausticPaths, nIndirectPaths, nDirectPaths;
+    SurfaceStores() : nCausticPaths(0), nIndirectPaths(0), nDirectPaths(0) {}
+};
+
 struct ShootTask {
     // PhotonShootingTask::Run locals (photonshooter.cpp:233-244)
     Rng rng;
@@ -150,9 +163,13 @@ struct ShootTask {
     bool causticDone, indirectDone, volumeDone, finished;
     std::vector<Photon> localVolume;
     uint32_t localCaustic, localDirect, localIndirect;
+    bool keepSurface;                                    // store the surface photons too (counted either way)
+    std::vector<Photon> localCausticP, localDirectP, localIndirectP;
+    std::vector<RadPhoton> localRad;
     ShootStats st;
     ShootTask(int taskNum, const pvol_params &p)
-        : rng(31u * (uint32_t)taskNum), halton(6, rng), totalPaths(0), finished(false), localCaustic(0), localDirect(0), localIndirect(0) {
+        : rng(31u * (uint32_t)taskNum), halton(6, rng), totalPaths(0), finished(false), localCaustic(0), localDirect(0), localIndirect(0),
+          keepSurface(false) {
         causticDone = (p.n_caustic_photons == 0);
         indirectDone = (p.n_indirect_photons == 0);
         volumeDone = (p.n_volume_photons == 0);
@@ -248,15 +265,27 @@ inline void follow_photon(const ShootShared &S, ShootTask &T, Ray photonRay, Hit
     V3 wo = -photonRay.d;
     if (hasNonSpecular) {
         bool deposited = false;
+        Photon photon;   // Photon(photonIsect.dg.p, alpha, wo), photonshooter.cpp:150
+        photon.p = photonIsect.p; photon.alpha = alpha; photon.wi = wo;
         if (specularPath && nIntersections > 1) {
-            if (!T.causticDone) { deposited = true; ++T.localCaustic; }
+            if (!T.causticDone) { deposited = true; ++T.localCaustic; if (T.keepSurface) T.localCausticP.push_back(photon); }
         } else {
-            if (nIntersections == 1 && !T.indirectDone && S.params->final_gather) { deposited = true; ++T.localDirect; }
-            else if (nIntersections > 1 && !T.indirectDone) { deposited = true; ++T.localIndirect; }
+            if (nIntersections == 1 && !T.indirectDone && S.params->final_gather) { deposited = true; ++T.localDirect; if (T.keepSurface) T.localDirectP.push_back(photon); }
+            else if (nIntersections > 1 && !T.indirectDone) { deposited = true; ++T.localIndirect; if (T.keepSurface) T.localIndirectP.push_back(photon); }
         }
         if (deposited && S.params->final_gather && T.rng.random_float() < .125f) {
             // two BSDF::rho(rng, ...) calls = 2 x 2 x StratifiedSample2D(6x6) = 288 RandomFloat (reflection.cpp:647-658)
             T.rng.skip(288);
+            if (T.keepSurface) {
+                // RadiancePhoton(p, Faceforward(nn, -photonRay.d)); rho_r / rho_t of the surface's BSDF: every non-specular
+                // BxDF on this path is a Lambertian, whose rho() is its reflectance whatever the samples (reflection.h:222-223)
+                RadPhoton rp;
+                rp.p = photonIsect.p;
+                rp.n = dot(photonIsect.nn, wo) < 0.f ? -photonIsect.nn : photonIsect.nn;
+                rp.rho_r = spec_const(0.f); rp.rho_t = spec_const(0.f);
+                if (mat.kind == PVOL_MATERIAL_MATTE) rp.rho_r = mat.kd;
+                T.localRad.push_back(rp);
+            }
         }
     }
     if (nIntersections >= S.params->max_photon_depth) return;
@@ -310,8 +339,9 @@ inline void shoot_block(const ShootShared &S, ShootTask &T) {
 // reference's mutex-ordered merge (photonshooter.cpp:280-351) made deterministic; nTasks == 1
 // reproduces --ncores 1 exactly.
 inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t nTasks, int nThreads,
-                         std::vector<Photon> *volumeOut, ShootStats *stats) {
+                         std::vector<Photon> *volumeOut, ShootStats *stats, SurfaceStores *surf = 0) {
     volumeOut->clear();
+    if (surf) *surf = SurfaceStores();
     *stats = ShootStats();
     if (scene.lights.empty()) return 0;  // photonshooter.cpp:459
     ShootShared S;
@@ -335,7 +365,7 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
     else { for (int i = 1; i < n + 1; ++i) S.lightCdf[i] /= S.lightFuncInt; }
 
     std::vector<ShootTask *> tasks;
-    for (uint32_t t = 0; t < nTasks; ++t) tasks.push_back(new ShootTask((int)t, params));
+    for (uint32_t t = 0; t < nTasks; ++t) { tasks.push_back(new ShootTask((int)t, params)); tasks.back()->keepSurface = surf != 0; }
     uint32_t nshot = 0;
     uint64_t nCaustic = 0, nIndirect = 0, nDirect = 0;
     bool abortTasks = false;
@@ -364,19 +394,28 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
                                    unsuccessful(params.n_indirect_photons, nIndirect, blockSize) ||
                                    unsuccessful(params.n_volume_photons, volumeOut->size(), blockSize))) {
                 volumeOut->clear(); nCaustic = nIndirect = 0;
+                if (surf) { surf->caustic.clear(); surf->indirect.clear(); surf->radiance.clear(); }
                 abortTasks = true; t->finished = true; rc = PVOL_E_SHOOT_FAILED;
                 continue;
             }
             nshot += blockSize;
             if (!t->indirectDone) {
+                if (surf) { surf->nIndirectPaths += blockSize; surf->nDirectPaths += blockSize;
+                            surf->indirect.insert(surf->indirect.end(), t->localIndirectP.begin(), t->localIndirectP.end());
+                            surf->direct.insert(surf->direct.end(), t->localDirectP.begin(), t->localDirectP.end()); }
                 nIndirect += t->localIndirect; t->localIndirect = 0;
                 if (nIndirect >= params.n_indirect_photons) t->indirectDone = true;
                 nDirect += t->localDirect; t->localDirect = 0;
             }
+            t->localIndirectP.clear(); t->localDirectP.clear();
             if (!t->causticDone) {
+                if (surf) { surf->nCausticPaths += blockSize; surf->caustic.insert(surf->caustic.end(), t->localCausticP.begin(), t->localCausticP.end()); }
                 nCaustic += t->localCaustic; t->localCaustic = 0;
                 if (nCaustic >= params.n_caustic_photons) t->causticDone = true;
             }
+            t->localCausticP.clear();
+            if (surf) surf->radiance.insert(surf->radiance.end(), t->localRad.begin(), t->localRad.end());   // always (photonshooter.cpp:341-349)
+            t->localRad.clear();
             if (!t->volumeDone) {
                 for (size_t i = 0; i < t->localVolume.size(); ++i) {
                     t->localVolume[i].alpha /= float(nshot);  // the RUNNING nshot (photonshooter.cpp:333)

@@ -66,7 +66,7 @@ def _worker_body(rank, world, port, strong, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     x0s, x1s, y0s, y1s, n_tiles = bench.frame_tiles(64, 36)
-    mine = np.arange(rank, n_tiles, world) if strong else np.arange(n_tiles)
+    mine = bench.partition_tasks(n_tiles, rank, world, weak=not strong)   # what bench.py gives this rank
     mine = mine[:6]   # keep the CPU suite short
     res = _march(mine, mine, spp=2)
     # the reductions bench.py performs: max-over-ranks time and total samples
@@ -109,6 +109,75 @@ def test_two_rank_tile_partition_matches_single_process(orc, strong):
         assert set(got[0][1]).isdisjoint(set(got[1][1]))
     else:
         assert set(got[0][1]) == set(got[1][1])
+
+
+def _film_worker(rank, world, port, q):
+    """bench.py's N > 1 default on CPU: this rank renders ITS share of one frame's render tasks (whole SamplerRendererTasks through
+    the oracle's tile driver, standing in for pvol_render_tasks_device) into its own film, then the films are summed with one
+    all-reduce -- the collective the GPU run issues over RCCL."""
+    try:
+        import importlib
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+        pvol = importlib.import_module("cs348b-pbrt_amd.pvol")
+        scene = load_scene("volumescene_h")
+        xres, yres, spp = 24, 16, 2
+        n_tiles = bench.frame_tiles(xres, yres)[4]
+        cam = abi.perspective_camera(float(scene["camera.fov"][0]), xres, yres, scene["camera.c2w"])
+        film = abi.make_film(xres, yres, orc.gaussian_filter_table())
+        smp = abi.make_sampler(xres, yres, spp, n_tiles)
+        mine = bench.partition_tasks(n_tiles, rank, world, weak=False).astype(np.uint32)
+        n_mine = pvol.render_sample_count(smp, mine)            # the library's own count of this rank's camera samples
+        o = orc.Oracle(abi.SceneHolder(scene), abi.params_from_blob(scene))
+        o.set_photons(*load_photons("vh"))
+        r = orc.render_tasks(o, cam, film, smp, mine, records=False)
+        assert r["n_samples"] == n_mine
+        px = torch.from_numpy(r["pixels"].copy())
+        dist.all_reduce(px, op=dist.ReduceOp.SUM)               # the film reduce
+        tot = torch.tensor([float(n_mine)], dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        q.put((rank, px.numpy(), int(tot.item()), [int(t) for t in mine[:3]], [int(e) for e in r["end_draws"][:3]]))
+        dist.destroy_process_group()
+    except Exception as e:   # noqa: BLE001
+        q.put((rank, "ERROR: %r" % (e,), 0, [], []))
+        raise
+
+
+def test_two_rank_film_reduce_equals_the_single_rank_frame(orc):
+    """The north_star's split end to end on CPU: render tasks round-robin over 2 ranks, one all-reduce of the film."""
+    import importlib
+    pvol = importlib.import_module("cs348b-pbrt_amd.pvol")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_film_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    assert not any(isinstance(g[1], str) for g in got), got
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    got.sort(key=lambda g: g[0])
+    scene = load_scene("volumescene_h")
+    xres, yres, spp = 24, 16, 2
+    n_tiles = bench.frame_tiles(xres, yres)[4]
+    cam = abi.perspective_camera(float(scene["camera.fov"][0]), xres, yres, scene["camera.c2w"])
+    film = abi.make_film(xres, yres, orc.gaussian_filter_table())
+    smp = abi.make_sampler(xres, yres, spp, n_tiles)
+    o = orc.Oracle(abi.SceneHolder(scene), abi.params_from_blob(scene))
+    o.set_photons(*load_photons("vh"))
+    whole = orc.render_tasks(o, cam, film, smp, np.arange(n_tiles, dtype=np.uint32), records=False)
+    assert got[0][2] == got[1][2] == whole["n_samples"] == pvol.render_sample_count(smp, np.arange(n_tiles, dtype=np.uint32)) == (xres + 5) * (yres + 5) * spp
+    assert got[0][3][0] == 0 and got[1][3][0] == 1                        # round-robin: rank r starts at task r
+    for rank, px, _, first, ends in got:
+        np.testing.assert_allclose(px, whole["pixels"], rtol=1e-5, atol=1e-6 * float(np.abs(whole["pixels"]).max()))
+        for t, e in zip(first, ends):                                     # a task's stream ends where it ends in the single-rank run
+            assert e == int(whole["end_draws"][t])
+    np.testing.assert_array_equal(got[0][1], got[1][1])                   # after the all-reduce both ranks hold the same film
 
 
 def test_tiles_cover_the_sample_extent_once():

@@ -248,6 +248,26 @@ def test_shooter_work_counters_equal_the_compiled_reference(orc):
     # the ratios are asserted on the committed 6 k map above.
 
 
+def test_oracle_surface_stores_are_what_it_counts(orc):
+    """The kept caustic / direct / indirect photons are exactly the deposits the counters (pinned above) count, every one on a
+    surface of the scene, with the arrival direction stored unit length; keeping them changes nothing about the volume map."""
+    s = load_scene("pinkfloyd")
+    h = abi.SceneHolder(s)
+    p = abi.params_from_blob(s, n_volume_photons=20000)
+    o = orc.Oracle(h, p)
+    o.keep_surface_photons(True)
+    assert o.shoot(1, 1) == 0
+    st = o.shoot_stats()
+    P, W, A, npaths = o.surface_photons(0)
+    assert len(P) == st["stored_caustic"] == 36953 and npaths == 4096      # causticphotons 1: done after the first block
+    np.testing.assert_allclose(np.linalg.norm(W, axis=1), 1.0, atol=1e-5)
+    assert (A >= 0).all() and ((A != 0).sum(axis=1) >= 1).all()
+    # the caustic photons of this scene land on the matte wall x = 5 (world) behind the prism
+    assert np.abs(P[:, 0] - 5.0).max() < 1e-3
+    assert len(o.surface_photons(1)[0]) == st["stored_direct"] == 0 and len(o.surface_photons(2)[0]) == st["stored_indirect"] == 0
+    assert len(o.get_photons()[0]) == 21038                                # as without the stores
+
+
 def test_shooter_is_deterministic_and_task_mode_differs(orc):
     s = load_scene("pinkfloyd")
     h = abi.SceneHolder(s)

@@ -128,6 +128,11 @@ def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     full = "--full" in sys.argv
+    if "--no-li" in sys.argv:   # frames only (kernel traces)
+        _run = run
+        def run(*a, **k):   # noqa: E731,F811
+            k.pop("li", None)
+            return _run(*a, **k)
     want = lambda c: not args or c in args   # noqa: E731
     if want("C1"):
         run("C1-h", "volumescene_h", 100000, 2048, "config 1 with Volume homogeneous (gather on), stated size", li=(256, 256, 16), frame=(256, 256, 16, True))

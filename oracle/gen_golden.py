@@ -138,6 +138,20 @@ def shoot(scene_name, n_photons, tag, n_tasks=1, **over):
     print("photons_%s: %d photons, %d paths" % (tag, len(P), st["paths"]))
 
 
+def shoot_caustic(scene_name, n_photons, tag, n_tasks=1, **over):
+    """The caustic store of the oracle shooter's run that also made photons_<tag> (same seeds, same paths): input of the
+    surface integrator's captures.  The reference's own shooter cannot be linked here (oracle/Makefile)."""
+    scene = blob.load(os.path.join(GOLD, "scene_%s.bin" % scene_name))
+    params = abi.params_from_blob(scene, n_volume_photons=n_photons, **over)
+    oc = orc.Oracle(abi.SceneHolder(scene), params)
+    oc.keep_surface_photons(True)
+    assert oc.shoot(n_tasks, 1) == 0
+    P, W, A, npaths = oc.surface_photons(0)
+    blob.save(os.path.join(GOLD, "caustic_%s.bin" % tag), {"p": P.reshape(-1), "wo": W.reshape(-1), "alpha": A.reshape(-1),
+                                                            "n_paths": np.array([npaths], np.uint32)})
+    print("caustic_%s: %d photons, %d paths" % (tag, len(P), npaths))
+
+
 def render_case(tag, scene_name, photons, xres, yres, spp, ntasks, tasks=None, **over):
     """Reference SamplerRendererTask loop (LDSampler + PerspectiveCamera + Li + ImageFilm), ref_capture `render`."""
     args = ["render", scene_name, os.path.join(GOLD, "photons_%s.bin" % photons) if photons else "-",
@@ -147,6 +161,14 @@ def render_case(tag, scene_name, photons, xres, yres, spp, ntasks, tasks=None, *
     for k, v in over.items():
         args += [k, v]
     cap(*args)
+
+
+def main_surface():
+    """SURVEY 8(f)-2, matte subset: the reference's PhotonIntegrator::Li (direct lighting + caustic estimate; the scene's
+    indirectphotons 0 leaves the final gather without a map) composed with the volume term as SamplerRenderer::Li does."""
+    shoot_caustic("volumescene_h", 6000, "vh")
+    render_case("vh_surf", "volumescene_h", "vh", 32, 18, 4, 8, surface=os.path.join(GOLD, "caustic_vh.bin"))
+    render_case("vh_surf64", "volumescene_h", "vh", 10, 6, 64, 4, tasks=[0, 2, 3], surface=os.path.join(GOLD, "caustic_vh.bin"))
 
 
 def main_hg():
@@ -161,6 +183,8 @@ def main_hg():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "hg":   # only the fixtures added in round 2
         return main_hg()
+    if len(sys.argv) > 1 and sys.argv[1] == "surface":
+        return main_surface()
     os.makedirs(GOLD, exist_ok=True)
     cap("tables", os.path.join(GOLD, "ref_tables.bin"))
     for s in ["volumescene_h", "volumescene_rainbow", "volumescene_grid16", "pinkfloyd", "shootbench"]:
@@ -189,6 +213,7 @@ def main():
     render_case("grid16", "volumescene_grid16", "grid16", 16, 10, 2, 4)
     render_case("pf", "pinkfloyd", "pf", 16, 16, 4, 4, nused=50, maxdist=0.25)
     main_hg()
+    main_surface()
 
 
 if __name__ == "__main__":

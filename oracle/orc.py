@@ -86,7 +86,8 @@ def lib():
         L.orc_film_add_samples.argtypes = [C.POINTER(abi.Film), _f32p, _f32p, C.c_uint32, C.c_uint64, _f32p]
         L.orc_film_resolve.argtypes = [C.POINTER(abi.Film), _f32p, _f32p]
         L.orc_render_tasks.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Film), C.POINTER(abi.Sampler), _u32p, C.c_uint32,
-                                       _f32p, C.c_void_p, _f32p, _f32p, _u64p, C.c_int]
+                                       _f32p, C.c_void_p, _f32p, _f32p, _u64p, C.c_int, _f32p]
+        L.orc_set_surface_integrator.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, _f32p, _f32p, _f32p, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
 
@@ -163,6 +164,19 @@ class Oracle:
         v = np.zeros(10, np.uint64)
         lib().orc_get_counters(self._h, _p(v, _u64p), int(reset))
         return dict(zip(COUNTER_NAMES, [int(x) for x in v]))
+
+    def set_surface_integrator(self, n_used=300, max_dist=0.15, final_gather=True, caustic=None, n_paths=0):
+        """PhotonIntegrator for render_tasks(): caustic = (p, wo, alpha) or None (no caustic map); None for n_used removes it."""
+        if n_used is None:
+            lib().orc_set_surface_integrator(self._h, 0, 0, 0.0, 0, None, None, None, 0, 0)
+            return
+        if caustic is None or len(caustic[0]) == 0:
+            lib().orc_set_surface_integrator(self._h, 1, n_used, max_dist, int(final_gather), None, None, None, 0, int(n_paths))
+            return
+        p = np.ascontiguousarray(caustic[0], np.float32).reshape(-1)
+        w = np.ascontiguousarray(caustic[1], np.float32).reshape(-1)
+        a = np.ascontiguousarray(caustic[2], np.float32).reshape(-1)
+        lib().orc_set_surface_integrator(self._h, 1, n_used, max_dist, int(final_gather), _p(p, _f32p), _p(w, _f32p), _p(a, _f32p), p.size // 3, int(n_paths))
 
     def shoot(self, n_tasks=1, n_threads=1):
         return lib().orc_shoot(self._h, n_tasks, n_threads)
@@ -244,8 +258,9 @@ def render_tasks(oracle, camera, film, sampler, task_ids, records=True, n_thread
     rays = np.zeros(n if records else 0, abi.RAY_DTYPE)
     xy = np.zeros((n if records else 0, 2), np.float32)
     xt = np.zeros((n if records else 0, 4), np.float32)
+    sx = np.zeros((n if records else 0, 3), np.float32)
     end = np.zeros(len(ids), np.uint64)
-    lib().orc_render_tasks(oracle._h, C.byref(camera), C.byref(film), C.byref(sampler), _p(ids, _u32p), len(ids), _p(pixels, _f32p),
-                           rays.ctypes.data if records else None, _p(xy, _f32p) if records else None, _p(xt, _f32p) if records else None,
-                           _p(end, _u64p), n_threads)
-    return {"pixels": pixels, "rays": rays, "image_xy": xy, "xyzT": xt, "end_draws": end, "n_samples": n}
+    rc = lib().orc_render_tasks(oracle._h, C.byref(camera), C.byref(film), C.byref(sampler), _p(ids, _u32p), len(ids), _p(pixels, _f32p),
+                                rays.ctypes.data if records else None, _p(xy, _f32p) if records else None, _p(xt, _f32p) if records else None,
+                                _p(end, _u64p), n_threads, _p(sx, _f32p) if records else None)
+    return {"pixels": pixels, "rays": rays, "image_xy": xy, "xyzT": xt, "surf_xyz": sx, "end_draws": end, "n_samples": n, "unsupported_hits": bool(rc)}

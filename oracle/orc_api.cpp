@@ -22,8 +22,13 @@ struct orc_ctx {
     ShootStats shoot_stats;
     bool keep_surface;
     SurfaceStores surf;
-    orc_ctx() : map(0), keep_surface(false) {}
-    ~orc_ctx() { delete map; }
+    // surface integrator (orc_surface.h), optional
+    bool have_si;
+    SurfaceIntegrator si;
+    std::vector<Photon> causticPhotons;
+    KdTree *causticMap;
+    orc_ctx() : map(0), keep_surface(false), have_si(false), causticMap(0) {}
+    ~orc_ctx() { delete map; delete causticMap; }
 };
 
 static Integrator make_integrator(const orc_ctx *c) {
@@ -386,10 +391,35 @@ void orc_film_resolve(const pvol_film *film, const float *pixels, float *rgb) {
 // n_threads <= 1; with more threads every thread owns a film and they are summed at the end (bench baseline).
 // rays/imageXY/xyzT (optional, sized for all samples) receive the per-sample records in task order; end_draws
 // (optional) one per task.
+// PhotonIntegrator (integrators/photonmap.cpp) for the tile driver: "nused", "maxdist", "finalgather" and a caustic map built
+// from n photons (p, wo: 3 floats, alpha: 30 floats each; n == 0: no map) shot over n_paths paths.  on == 0 removes it.
+int orc_set_surface_integrator(orc_ctx *c, int on, int n_used, float max_dist, int final_gather, const float *p, const float *wo,
+                               const float *alpha, uint32_t n, uint32_t n_paths) {
+    delete c->causticMap;
+    c->causticMap = 0;
+    c->causticPhotons.clear();
+    c->have_si = on != 0;
+    if (!on) return 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        Photon ph;
+        ph.p = v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+        ph.wi = v3(wo[3 * i], wo[3 * i + 1], wo[3 * i + 2]);
+        memcpy(ph.alpha.c, alpha + (size_t)i * NB, sizeof(float) * NB);
+        c->causticPhotons.push_back(ph);
+    }
+    if (n) c->causticMap = new KdTree(c->causticPhotons);
+    c->si.nLookup = n_used; c->si.maxDistSquared = max_dist * max_dist; c->si.maxSpecularDepth = 5; c->si.finalGather = final_gather != 0;
+    c->si.causticMap = c->causticMap; c->si.nCausticPaths = (int)n_paths;
+    return 0;
+}
+
+// returns 0, or 1 when a camera ray met a surface the surface integrator's restatement does not cover (specular BSDF)
 int orc_render_tasks(orc_ctx *c, const pvol_camera *cam, const pvol_film *film, const pvol_sampler *smp, const uint32_t *task_ids,
-                     uint32_t n_task_ids, float *pixels, pvol_ray *rays, float *imageXY, float *xyzT, uint64_t *end_draws, int n_threads) {
+                     uint32_t n_task_ids, float *pixels, pvol_ray *rays, float *imageXY, float *xyzT, uint64_t *end_draws, int n_threads,
+                     float *surfXYZ) {
     Integrator I = make_integrator(c);
-    const bool wantRec = rays || imageXY || xyzT;
+    const bool wantRec = rays || imageXY || xyzT || surfXYZ;
+    std::atomic<int> unsupported(0);
     std::vector<uint64_t> first(n_task_ids + 1, 0);
     for (uint32_t i = 0; i < n_task_ids; ++i) {
         int32_t w[4];
@@ -407,9 +437,12 @@ int orc_render_tasks(orc_ctx *c, const pvol_camera *cam, const pvol_film *film, 
             uint32_t i = next.fetch_add(1);
             if (i >= n_task_ids) break;
             std::vector<pvol_ray> r;
-            std::vector<float> xy, xt;
-            TileRecords rec = {&r, &xy, &xt};
-            uint64_t d = render_task(I, *cam, *smp, task_ids[i], pixels ? &F : 0, wantRec ? &rec : 0, &local);
+            std::vector<float> xy, xt, sx;
+            TileRecords rec = {&r, &xy, &xt, (surfXYZ && c->have_si) ? &sx : 0};
+            bool sup = true;
+            uint64_t d = render_task(I, *cam, *smp, task_ids[i], pixels ? &F : 0, wantRec ? &rec : 0, &local, c->have_si ? &c->si : 0, &sup);
+            if (!sup) unsupported = 1;
+            if (surfXYZ && c->have_si) memcpy(surfXYZ + 3 * first[i], sx.data(), sizeof(float) * sx.size());
             if (end_draws) end_draws[i] = d;
             if (rays) memcpy(rays + first[i], r.data(), sizeof(pvol_ray) * r.size());
             if (imageXY) memcpy(imageXY + 2 * first[i], xy.data(), sizeof(float) * xy.size());
@@ -425,7 +458,7 @@ int orc_render_tasks(orc_ctx *c, const pvol_camera *cam, const pvol_film *film, 
         for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, false);
         for (auto &t : th) t.join();
     }
-    return 0;
+    return unsupported.load();
 }
 
 }  // extern "C"

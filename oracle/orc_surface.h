@@ -1,0 +1,93 @@
+// orc_surface.h -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+//
+// PhotonIntegrator::Li (integrators/photonmap.cpp:154-319) for the part of SURVEY 8(f)-2 the product implements: camera rays
+// that end on NON-SPECULAR surfaces (the matte walls of both BASELINE scenes), no indirect map (both scenes set
+// `indirectphotons 0`, which leaves the final gather and the indirect estimate without a map, photonmap.cpp:183,315).
+// What remains is
+//   L = UniformSampleAllLights (core/integrator.cpp:47-79 -> EstimateDirect :117-174, delta lights)
+//     + LPhoton(causticMap)     (photonmap.cpp:62-108, diffuse branch)
+// and the RNG traffic of the rest: two BSDF::rho(wo, rng) inside LPhoton (2 x 72 draws, core/reflection.cpp:660-670), two
+// BSDFSample(rng) of SpecularReflect / SpecularTransmit (2 x 3 draws, core/integrator.cpp:184,225), one draw per unoccluded
+// light sample (visibility.Transmittance(..., NULL, rng), core/integrator.cpp:133).  Pinned by the reference's own records
+// (tests/golden/render_vh_surf*.bin, written by oracle/ref_capture.cpp `render ... surface`).
+#ifndef ORC_SURFACE_H
+#define ORC_SURFACE_H
+#include "orc_integrator.h"
+
+namespace orc {
+
+struct SurfaceIntegrator {
+    int nLookup;               // "nused"
+    float maxDistSquared;      // "maxdist"^2
+    int maxSpecularDepth;      // "maxspeculardepth" (5)
+    bool finalGather;
+    const KdTree *causticMap;  // may be NULL
+    int nCausticPaths;
+};
+
+// BSDF::f(wo, wi, flags) of a matte surface (core/reflection.cpp:627-644 + Lambertian::f :212-214): the Lambertian lobe
+// counts only when wi and wo lie on the same side of the geometric normal
+inline Spec matte_f(const Material &m, V3 ng, V3 woW, V3 wiW) {
+    if (!(dot(wiW, ng) * dot(woW, ng) > 0.f)) return spec_const(0.f);   // BSDF_REFLECTION is masked out otherwise
+    return m.kd * kInvPi;
+}
+
+// photonmap.cpp:56-60
+inline float photon_kernel(V3 photonP, V3 p, float maxDist2) {
+    float s = (1.f - length_sq(photonP - p) / maxDist2);
+    return 3.f * kInvPi * s * s;
+}
+
+// Returns Li of the surface integrator at a hit of `ray`; advances rng exactly as the reference does.  `supported` is cleared
+// when the hit needs what this restatement leaves out (a specular BSDF: the recursion of SpecularReflect/Transmit).
+inline Spec surface_li(const Integrator &I, const SurfaceIntegrator &S, const Ray &ray, const Hit &isect, Rng &rng, Counters *ctr,
+                       std::vector<ClosePhoton> &lookupBuf, bool *supported) {
+    const Scene &sc = *I.scene;
+    const Material &mat = sc.mats[sc.tris[isect.tri].material];
+    Spec L = spec_const(0.f);
+    if (mat.kind != PVOL_MATERIAL_MATTE) { if (supported) *supported = false; return L; }
+    const bool hasLambert = !is_black(mat.kd);   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd (matte.cpp:55-60)
+    const V3 wo = -ray.d;
+    const V3 p = isect.p, n = isect.nn;          // dgShading == dg for a triangle without normals
+    // ---- UniformSampleAllLights: one sample per delta light
+    for (size_t li = 0; li < sc.lights.size(); ++li) {
+        V3 wi; float lightPdf; Ray vis;
+        Spec Li = light_sample_L(sc.lights[li], p, isect.rayEpsilon, ray.time, &wi, &lightPdf, &vis);
+        Spec Ld = spec_const(0.f);
+        if (lightPdf > 0. && !is_black(Li)) {
+            Spec f = matte_f(mat, n, wo, wi);
+            if (!is_black(f) && !scene_intersect_p(sc, vis)) {
+                Li = Li * transmittance(I, vis, rng, ctr);                   // sample == NULL: one draw
+                Ld = Ld + f * Li * (fabsf(dot(wi, n)) / lightPdf);          // IsDeltaLight()
+            }
+        }
+        L = L + Ld / 1.f;                                                   // nSamples == 1
+    }
+    // ---- caustic estimate: LPhoton, diffuse branch (the matte BSDF has no glossy / transmissive component)
+    if (S.causticMap && hasLambert) {   // LPhoton: `map && bsdf->NumComponents(nonSpecular) > 0` (photonmap.cpp:68)
+        if ((int)lookupBuf.size() < S.nLookup) lookupBuf.resize(S.nLookup);
+        PhotonProcess proc;
+        proc.photons = &lookupBuf[0]; proc.nLookup = (uint32_t)S.nLookup; proc.nFound = 0; proc.ctr = 0;
+        float maxDist2 = S.maxDistSquared;
+        kd_lookup(*S.causticMap, 0, p, proc, maxDist2);
+        const V3 Nf = dot(n, wo) < 0.f ? -n : n;                            // Faceforward(nn, wo)
+        Spec Lr = spec_const(0.f), Lt = spec_const(0.f);
+        for (uint32_t i = 0; i < proc.nFound; ++i) {
+            const Photon &ph = S.causticMap->data[proc.photons[i].photon];
+            float k = photon_kernel(ph.p, p, maxDist2);
+            if (dot(Nf, ph.wi) > 0.f) Lr = Lr + (k / (S.nCausticPaths * maxDist2)) * ph.alpha;
+            else Lt = Lt + (k / (S.nCausticPaths * maxDist2)) * ph.alpha;
+        }
+        rng.skip(72);                                                       // bsdf->rho(wo, rng, BSDF_ALL_REFLECTION): 6x6 jittered samples, unused by Lambertian::rho
+        const Spec rhoR = mat.kd;                                           // Lambertian::rho == R (reflection.h:222-223)
+        rng.skip(72);                                                       // bsdf->rho(wo, rng, BSDF_ALL_TRANSMISSION): no such component -> 0
+        L = L + Lr * rhoR * kInvPi + Lt * spec_const(0.f) * kInvPi;
+    }
+    // indirect: finalGather && indirectMap != NULL is false without an indirect map; LPhoton(NULL map) adds nothing, draws nothing
+    // ---- SpecularReflect + SpecularTransmit: BSDFSample(rng) is constructed before Sample_f finds no specular component
+    if (0 + 1 < S.maxSpecularDepth) rng.skip(6);
+    return L;
+}
+
+}  // namespace orc
+#endif

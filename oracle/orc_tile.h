@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "orc_integrator.h"
+#include "orc_surface.h"
 
 namespace orc {
 
@@ -154,12 +155,15 @@ struct Film {
 struct TileRecords {   // optional per-sample records of render_task
     std::vector<pvol_ray> *rays;
     std::vector<float> *imageXY, *xyzT;
+    std::vector<float> *surfXYZ;   // surface integrator's Li as X, Y, Z (only with a surface integrator)
 };
 
 // SamplerRendererTask::Run, renderers/samplerrenderer.cpp:59-157, with Ls = Lvi (no surface term) and the
 // unexpected-radiance guards of :118-133.  Returns the number of RandomUInt draws the task made.
+// With a surface integrator `SI` the sample's radiance is T * Lsurface + Lvi as SamplerRenderer::Li composes it
+// (samplerrenderer.cpp:238-250), the surface term first (it draws before the volume integrator does).
 inline uint64_t render_task(const Integrator &I, const pvol_camera &cam, const pvol_sampler &smp, uint32_t taskNum, Film *film,
-                            TileRecords *rec, Counters *ctr) {
+                            TileRecords *rec, Counters *ctr, const SurfaceIntegrator *SI = 0, bool *supported = 0) {
     int32_t w[4];
     compute_sub_window(smp, taskNum, w);
     if (w[0] == w[1] || w[2] == w[3]) return 0;   // GetSubSampler returns NULL (lowdiscrepancy.cpp:61-66): no RNG either
@@ -176,9 +180,14 @@ inline uint64_t render_task(const Integrator &I, const pvol_camera &cam, const p
             for (uint32_t i = 0; i < smp.pixel_samples; ++i) {
                 Ray ray = camera_ray(cam, ps.imageX[i], ps.imageY[i], ps.time[i]);
                 Hit hit;
-                scene_intersect(*I.scene, &ray, &hit);   // SamplerRenderer::Li, samplerrenderer.cpp:236-249: clips ray.maxt
+                const bool hitSurface = scene_intersect(*I.scene, &ray, &hit);   // SamplerRenderer::Li, samplerrenderer.cpp:236-249: clips ray.maxt
+                Spec Lsurf = spec_const(0.f);
+                const uint64_t ds0 = rng.draws;
+                if (SI && hitSurface) Lsurf = surface_li(I, *SI, ray, hit, rng, ctr, lookupBuf, supported);
+                const uint64_t surfDraws = rng.draws - ds0;
                 Spec T;
                 Spec Lv = li(I, ray, ps.scatter[i], rng, &T, ctr, scratch, lookupBuf);
+                if (SI) Lv = T * Lsurf + Lv;
                 bool bad = false;
                 for (int b = 0; b < NB; ++b) if (std::isnan(Lv.c[b])) bad = true;
                 float y = spec_y(cie, Lv);
@@ -192,11 +201,12 @@ inline uint64_t render_task(const Integrator &I, const pvol_camera &cam, const p
                     pr.o[0] = ray.o.x; pr.o[1] = ray.o.y; pr.o[2] = ray.o.z;
                     pr.d[0] = ray.d.x; pr.d[1] = ray.d.y; pr.d[2] = ray.d.z;
                     pr.mint = ray.mint; pr.maxt = ray.maxt; pr.time = ray.time; pr.scatter_u = ps.scatter[i];
-                    pr.rng_skip = (i == 0) ? (uint32_t)samplerDraws : 0u;
+                    pr.rng_skip = ((i == 0) ? (uint32_t)samplerDraws : 0u) + (uint32_t)surfDraws;
                     rec->rays->push_back(pr);
                     rec->imageXY->push_back(ps.imageX[i]); rec->imageXY->push_back(ps.imageY[i]);
                     rec->xyzT->push_back(xyz[0]); rec->xyzT->push_back(xyz[1]); rec->xyzT->push_back(xyz[2]);
                     rec->xyzT->push_back(spec_y(cie, T));
+                    if (rec->surfXYZ) { float sx[3]; spec_xyz(cie, Lsurf, sx); rec->surfXYZ->push_back(sx[0]); rec->surfXYZ->push_back(sx[1]); rec->surfXYZ->push_back(sx[2]); }
                 }
             }
         }

@@ -54,6 +54,7 @@
 #include "texture.h"
 #include "photonshooter.h"
 #include "integrators/photonvolume.h"
+#include "integrators/photonmap.h"
 #include "accelerators/bvh.h"
 #include "lights/distant.h"
 #include "lights/point.h"
@@ -426,13 +427,25 @@ static void flatten(const BuiltScene &B, Blob &out, bool withDensity) {
 // forwards to the volume integrator.  SamplerRenderer itself cannot be linked (task system).
 class CaptureRenderer : public Renderer {
 public:
-    explicit CaptureRenderer(VolumeIntegrator *v) : vi(v) {}
+    explicit CaptureRenderer(VolumeIntegrator *v, SurfaceIntegrator *s = NULL) : vi(v), si(s) {}
     void Render(const Scene *) {}
-    Spectrum Li(const Scene *, const RayDifferential &, const Sample *, RNG &, MemoryArena &, Intersection *, Spectrum *) const { return 0.f; }
+    // SamplerRenderer::Li (renderers/samplerrenderer.cpp:228-251), reached only from the surface integrator's specular bounces
+    Spectrum Li(const Scene *scene, const RayDifferential &ray, const Sample *sample, RNG &rng, MemoryArena &arena, Intersection *isect, Spectrum *T) const {
+        Spectrum localT;
+        if (!T) T = &localT;
+        Intersection localIsect;
+        if (!isect) isect = &localIsect;
+        Spectrum L = 0.f;
+        if (scene->Intersect(ray, isect)) { if (si) L = si->Li(scene, this, ray, *isect, sample, rng, arena); }
+        else for (uint32_t i = 0; i < scene->lights.size(); ++i) L += scene->lights[i]->Le(ray);
+        Spectrum Lvi = vi->Li(scene, this, ray, sample, rng, T, arena);
+        return *T * L + Lvi;
+    }
     Spectrum Transmittance(const Scene *scene, const RayDifferential &ray, const Sample *sample, RNG &rng, MemoryArena &arena) const {
         return vi->Transmittance(scene, this, ray, sample, rng, arena);
     }
     VolumeIntegrator *vi;
+    SurfaceIntegrator *si;
 };
 
 static uint64_t drawsBetween(RNG &shadow, const RNG &live, uint64_t limit) {
@@ -632,6 +645,13 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     memset(&B.nx, 0, sizeof(int) * 3);
     if (!buildByName(B, name)) return 1;
     int xres = 32, yres = 18, spp = 4, nTasks = 8;
+    // `surface CAUSTIC.bin`: also run the reference's PhotonIntegrator (integrators/photonmap.cpp) with the scene's own
+    // SurfaceIntegrator parameters on a caustic map built from the given photons (oracle-shot: the reference's shooter does
+    // not link here); Ls then is T * Lsurface + Lvi as SamplerRenderer::Li composes it
+    const char *causticPath = NULL;
+    int surfNused = 300, surfGatherSamples = 64;
+    float surfMaxDist = .15f;
+    bool surfFinalGather = true;
     std::vector<uint32_t> tasks;
     for (int i = 0; i + 1 < argc; i += 2) {
         if (!strcmp(argv[i], "stepsize")) B.stepSize = (float)atof(argv[i + 1]);
@@ -641,6 +661,10 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
         else if (!strcmp(argv[i], "yres")) yres = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "spp")) spp = atoi(argv[i + 1]);
         else if (!strcmp(argv[i], "ntasks")) nTasks = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "surface")) causticPath = argv[i + 1];
+        else if (!strcmp(argv[i], "surfnused")) surfNused = atoi(argv[i + 1]);
+        else if (!strcmp(argv[i], "surfmaxdist")) surfMaxDist = (float)atof(argv[i + 1]);
+        else if (!strcmp(argv[i], "surffinalgather")) surfFinalGather = atoi(argv[i + 1]) != 0;
         else if (!strcmp(argv[i], "tasks")) {
             const char *q = argv[i + 1];
             while (*q) { tasks.push_back((uint32_t)strtoul(q, (char **)&q, 10)); if (*q == ',') ++q; }
@@ -664,7 +688,27 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     vp.AddInt("nused", &B.nUsed, 1);
     vp.AddFloat("maxdist", &B.maxDist, 1);
     PhotonVolumeIntegrator *vi = CreatePhotonVolumeIntegrator(vp, psh);
-    CaptureRenderer renderer(vi);
+    PhotonIntegrator *si = NULL;
+    Blob cb;
+    if (causticPath) {
+        if (strcmp(causticPath, "-")) {
+            if (!cb.load(causticPath)) { fprintf(stderr, "cannot read %s\n", causticPath); return 1; }
+            size_t m = cb.get("p").count() / 3;
+            const float *pp = cb.get("p").f32(), *pw = cb.get("wo").f32(), *pa = cb.get("alpha").f32();
+            vector<Photon> photons;
+            for (size_t i = 0; i < m; ++i)
+                photons.push_back(Photon(Point(pp[3 * i], pp[3 * i + 1], pp[3 * i + 2]), specFrom(pa + 30 * i), Vector(pw[3 * i], pw[3 * i + 1], pw[3 * i + 2])));
+            if (m) psh->causticMap = new KdTree<Photon>(photons);
+            psh->nCausticPaths = (int)cb.get("n_paths").u32()[0];
+        }
+        ParamSet sp;
+        sp.AddInt("nused", &surfNused, 1);
+        sp.AddFloat("maxdist", &surfMaxDist, 1);
+        sp.AddBool("finalgather", &surfFinalGather, 1);
+        sp.AddInt("finalgathersamples", &surfGatherSamples, 1);
+        si = CreatePhotonMapSurfaceIntegrator(sp, psh);
+    }
+    CaptureRenderer renderer(vi, si);
 
     // Film "image" + PixelFilter "gaussian" (defaults), Camera "perspective", Sampler "lowdiscrepancy": core/api.cpp:1221-1288
     ParamSet filtp, filmp, camp, sampp;
@@ -680,7 +724,7 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     PerspectiveCamera *camera = CreatePerspectiveCamera(camp, ac2w, film);
     sampp.AddInt("pixelsamples", &spp, 1);
     LDSampler *mainSampler = CreateLowDiscrepancySampler(sampp, film, camera);
-    Sample *origSample = new Sample(mainSampler, NULL, vi, B.scene);
+    Sample *origSample = new Sample(mainSampler, si, vi, B.scene);
 
     Blob out;
     std::vector<float> r2c, c2wm, ftab(film->filterTable, film->filterTable + 256);
@@ -696,8 +740,8 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     int32_t ext[4];
     film->GetSampleExtent(&ext[0], &ext[1], &ext[2], &ext[3]);
     out.put("sampler.extent", blob::I32, ext, 4);
-    int32_t si[6] = {xres, yres, mainSampler->samplesPerPixel, nTasks, (int32_t)vi->tauSampleOffset, (int32_t)vi->scatterSampleOffset};
-    out.put("sampler.i", blob::I32, si, 6);
+    int32_t smpI[6] = {xres, yres, mainSampler->samplesPerPixel, nTasks, (int32_t)vi->tauSampleOffset, (int32_t)vi->scatterSampleOffset};
+    out.put("sampler.i", blob::I32, smpI, 6);
     std::vector<uint32_t> n1d(origSample->n1D.begin(), origSample->n1D.end()), n2d(origSample->n2D.begin(), origSample->n2D.end());
     out.putu("sampler.n1d", n1d);
     out.putu("sampler.n2d", n2d);
@@ -706,8 +750,8 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     out.putf("params.f", pf, 3);
     out.puti1("params.nused", B.nUsed);
 
-    std::vector<float> sImg, sTime, sLens, sTau, sScat, rayO, rayD, rayT, xyzT;
-    std::vector<uint32_t> skip, nextRng, nSamples;
+    std::vector<float> sImg, sTime, sLens, sTau, sScat, rayO, rayD, rayT, xyzT, surfXYZ;
+    std::vector<uint32_t> skip, nextRng, nSamples, surfDraws;
     std::vector<int32_t> windows;
     std::vector<uint64_t> endDraws;
     MemoryArena arena;
@@ -733,9 +777,14 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
                 float rayWeight = camera->GenerateRayDifferential(samples[i], &ray);
                 ray.ScaleDifferentials(1.f / sqrtf(sampler->samplesPerPixel));
                 Intersection isect;
-                B.scene->Intersect(ray, &isect);                      // SamplerRenderer::Li, samplerrenderer.cpp:236-249
+                Spectrum Lsurf(0.f);
+                const bool hitSurface = B.scene->Intersect(ray, &isect);   // SamplerRenderer::Li, samplerrenderer.cpp:236-249
+                if (hitSurface && si) Lsurf = si->Li(B.scene, &renderer, ray, isect, &samples[i], rng, arena);
+                const uint64_t dsurf = si ? drawsBetween(shadow, rng, 100000000) : 0;
+                total += dsurf;
                 Spectrum T(1.f);
-                Spectrum Ls = rayWeight * vi->Li(B.scene, &renderer, ray, &samples[i], rng, &T, arena);
+                Spectrum Lvi = vi->Li(B.scene, &renderer, ray, &samples[i], rng, &T, arena);
+                Spectrum Ls = rayWeight * (T * Lsurf + Lvi);
                 if (Ls.HasNaNs() || Ls.y() < -1e-5 || isinf(Ls.y())) Ls = Spectrum(0.f);
                 uint64_t d = drawsBetween(shadow, rng, 100000000);
                 total += d;
@@ -751,7 +800,8 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
                 rayD.push_back(ray.d.x); rayD.push_back(ray.d.y); rayD.push_back(ray.d.z);
                 rayT.push_back(ray.mint); rayT.push_back(ray.maxt);
                 xyzT.push_back(xyz[0]); xyzT.push_back(xyz[1]); xyzT.push_back(xyz[2]); xyzT.push_back(T.y());
-                skip.push_back(i == 0 ? (uint32_t)ds : 0u);
+                skip.push_back((i == 0 ? (uint32_t)ds : 0u) + (uint32_t)dsurf);   // what the caller drew in front of this sample's volume Li()
+                if (si) { float sx[3]; Lsurf.ToXYZ(sx); surfXYZ.push_back(sx[0]); surfXYZ.push_back(sx[1]); surfXYZ.push_back(sx[2]); surfDraws.push_back((uint32_t)dsurf); }
                 ++count;
             }
             if (sampler->ReportResults(samples, NULL, NULL, NULL, sampleCount))   // samplerrenderer.cpp:137-146
@@ -767,6 +817,13 @@ static int cmdRender(const std::string &name, const char *photonPath, const char
     out.putf("samples.tau", sTau); out.putf("samples.scatter", sScat);
     out.putf("rays.o", rayO); out.putf("rays.d", rayD); out.putf("rays.t", rayT); out.putf("xyzT", xyzT);
     out.putu("rays.skip", skip); out.putu("next_rng", nextRng); out.putu("task.n_samples", nSamples);
+    if (si) {
+        out.putf("surf.xyz", surfXYZ); out.putu("surf.draws", surfDraws);
+        float sf[1] = {surfMaxDist};
+        int32_t sn[3] = {surfNused, surfFinalGather ? 1 : 0, psh->nCausticPaths};
+        out.putf("surf.params.f", sf, 1);
+        out.put("surf.params.i", blob::I32, sn, 3);
+    }
     out.put("task.window", blob::I32, windows.data(), windows.size());
     out.put("task.end_draw", blob::U64, endDraws.data(), endDraws.size());
     std::vector<float> pix;

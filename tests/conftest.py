@@ -77,12 +77,14 @@ RENDER_CASES = {
     "grid16": ("volumescene_grid16", "grid16"),   # VolumeGrid: fused RESOLVE pre-pass + replay
     "pf": ("pinkfloyd", "pf"),              # spot light through a glass prism's triangles
 }
+# the same with the reference's surface integrator in place (ref_capture `render ... surface`): scene, photon map tag
+RENDER_SURF_CASES = {"vh_surf": ("volumescene_h", "vh"), "vh_surf64": ("volumescene_h", "vh")}
 
 
 def load_render_case(name):
     """Returns (scene blob, params, camera, film, sampler, case blob) for a golden render case."""
     c = blob.load(os.path.join(GOLD, "render_%s.bin" % name))
-    s = load_scene(RENDER_CASES[name][0])
+    s = load_scene((RENDER_CASES[name] if name in RENDER_CASES else RENDER_SURF_CASES[name])[0])
     p = abi.params_from_blob(s, step_size=float(c["params.f"][0]), max_dist=float(c["params.f"][1]),
                              n_used=int(c["params.nused"][0]))
     si = c["sampler.i"]

@@ -317,6 +317,29 @@ def test_render_task_records_match_reference(orc, name):
     assert np.isfinite(c["film.rgb"]).all() and c["film.rgb"].max() > 0
 
 
+@pytest.mark.parametrize("name", ["vh_surf", "vh_surf64"])
+def test_render_with_the_surface_integrator_matches_reference(orc, name):
+    """SURVEY 8(f)-2, matte subset: whole SamplerRendererTasks with the reference's PhotonIntegrator in place (direct lighting,
+    caustic estimate, and every RNG draw of the rest of its Li()): per-sample surface radiance, the composed T * Ls + Lvi, the
+    draws in front of every volume Li(), the stream ends and the film are the reference's, bit for bit."""
+    s, p, cam, film, smp, c = load_render_case(name)
+    cb = blob.load(os.path.join(GOLD, "caustic_vh.bin"))
+    o = orc.Oracle(abi.SceneHolder(s), p)
+    o.set_photons(*load_photons("vh"))
+    o.set_surface_integrator(int(c["surf.params.i"][0]), float(c["surf.params.f"][0]), bool(c["surf.params.i"][1]),
+                             (cb["p"].reshape(-1, 3), cb["wo"].reshape(-1, 3), cb["alpha"].reshape(-1, 30)), int(cb["n_paths"][0]))
+    assert int(c["surf.params.i"][2]) == int(cb["n_paths"][0])
+    r = orc.render_tasks(o, cam, film, smp, c["tasks"])
+    assert not r["unsupported_hits"]
+    np.testing.assert_array_equal(r["rays"]["rng_skip"], c["rays.skip"])          # sampler draws + the surface integrator's
+    np.testing.assert_array_equal(r["end_draws"], c["task.end_draw"])
+    np.testing.assert_array_equal(r["surf_xyz"].ravel(), c["surf.xyz"])
+    np.testing.assert_array_equal(r["xyzT"].ravel(), c["xyzT"])
+    np.testing.assert_array_equal(r["pixels"].ravel(), c["film.pixels"])
+    assert set(np.unique(c["surf.draws"])) <= {0, 150, 151}                       # 144 (2 x rho) + 6 (2 x BSDFSample) + unoccluded light
+    assert (c["surf.xyz"].reshape(-1, 3).sum(1) > 0).mean() > 0.5
+
+
 def test_ld_pixel_sample_and_filter_table_match_reference(orc):
     s, p, cam, film, smp, c = load_render_case("vh")
     np.testing.assert_array_equal(orc.gaussian_filter_table(2.0, 2.0, 2.0), c["film.filter_table"])

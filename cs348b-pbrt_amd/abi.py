@@ -239,7 +239,13 @@ class Sampler(C.Structure):
 
 
 class RenderDebug(C.Structure):
-    _fields_ = [("d_rays", C.c_void_p), ("d_image_xy", C.c_void_p), ("d_xyz", C.c_void_p), ("d_streams", C.c_void_p)]
+    _fields_ = [("d_rays", C.c_void_p), ("d_image_xy", C.c_void_p), ("d_xyz", C.c_void_p), ("d_streams", C.c_void_p),
+                ("d_surf_xyz", C.c_void_p)]
+
+
+class SurfaceParams(C.Structure):   # pvol_surface_params
+    _fields_ = [("n_used", C.c_int32), ("max_dist", C.c_float), ("max_specular_depth", C.c_int32), ("final_gather", C.c_int32),
+                ("n_caustic_paths", C.c_uint32), ("use_preprocess_store", C.c_int32), ("reserved", C.c_uint32 * 2)]
 
 
 def make_camera(raster_to_camera, camera_to_world, shutter_open=0.0, shutter_close=1.0, lens_radius=0.0, focal_distance=1e30):

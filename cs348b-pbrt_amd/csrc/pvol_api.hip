@@ -120,6 +120,8 @@ void pvol_destroy(pvol_ctx *c) {
     hipDeviceSynchronize();
     pvol_free_photons(c);
     pvol_free_surface_stores(c);
+    pvol_free_caustic_map(c);
+    if (c->dTau) hipFree(c->dTau);
     for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->dDensity) hipFree(c->dDensity);
@@ -235,6 +237,8 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         if (k != PVOL_LIGHT_POINT && k != PVOL_LIGHT_SPOT && k != PVOL_LIGHT_DISTANT) return PVOL_E_UNSUPPORTED;
     }
     DevScene h = c->hs;   // keeps the photon-map fields, everything else is replaced
+    memset(&h.surf, 0, sizeof(h.surf));   // the surface integrator belongs to the scene it was enabled on
+    h.shootScene = c->dsh;
     h.volKind = v.kind;
     for (int i = 0; i < 3; ++i) { h.extLo[i] = v.extent_min[i]; h.extHi[i] = v.extent_max[i]; }
     memcpy(h.w2v, v.world_to_volume, sizeof(h.w2v));
@@ -307,6 +311,7 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     if (c->dDensity) hipFree(c->dDensity);
     c->dDensity = newDensity;
     c->maxDensity = maxDensity;
+    pvol_free_caustic_map(c);   // the surface integrator belongs to the scene it was enabled on (h.surf is zero)
     c->hs = h;
     c->hsh = hsh;
     c->haveScene = true;
@@ -383,6 +388,92 @@ int pvol_upload_photons(pvol_ctx *c, const float *p, const float *wi, const floa
            ok(hipMemcpy(c->dRawAlpha, alpha, sizeof(float) * 30 * (size_t)n, hipMemcpyHostToDevice));
     if (!good) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
     return pvol_finish_map(c, n, p);
+}
+
+void pvol_free_caustic_map(pvol_ctx *c) {
+    if (c->dCPos4) hipFree(c->dCPos4);
+    if (c->dCAlpha4) hipFree(c->dCAlpha4);
+    if (c->dCWi4) hipFree(c->dCWi4);
+    if (c->dCCellStart) hipFree(c->dCCellStart);
+    c->dCPos4 = c->dCAlpha4 = c->dCWi4 = 0; c->dCCellStart = 0;
+    memset(&c->hs.surf, 0, sizeof(c->hs.surf));
+}
+
+// PhotonIntegrator::Li in front of the volume term (include/pvol.h).  The caustic map gets the volume map's cell layout
+// (pvol_grid.hip) with cells of about maxdist / 2: a lookup gathers everything within maxdist, never fewer.
+int pvol_set_surface_integrator(pvol_ctx *c, const pvol_surface_params *sp, const float *p, const float *wo, const float *alpha, uint32_t n) {
+    if (!c) return PVOL_E_INVALID;
+    if (!c->haveScene) return PVOL_E_NO_SCENE;
+    std::lock_guard<std::recursive_mutex> api(c->apiMu);
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    if (!sp) {
+        hipDeviceSynchronize();
+        pvol_free_caustic_map(c);
+        return pvol_push_scene(c);
+    }
+    if (sp->n_used < 1 || !(sp->max_dist > 0.f) || sp->max_specular_depth < 0) return PVOL_E_INVALID;
+    // the matte subset: a specular BSDF would need the recursion of SpecularReflect / SpecularTransmit (core/integrator.cpp:177-262)
+    for (int i = 0; i < c->hs.nTris; ++i)
+        if (c->hsh.mats[c->hsh.triMat[i]].kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
+    uint32_t nPaths = sp->n_caustic_paths;
+    std::vector<float> hp;
+    const float *dP = 0, *dWo = 0, *dAlpha = 0;
+    float *up[3] = {0, 0, 0};
+    auto drop = [&]() { for (int i = 0; i < 3; ++i) if (up[i]) hipFree(up[i]); };
+    if (sp->use_preprocess_store) {   // device to device; the positions come back once for the grid bounds
+        const pvol_ctx::SurfStore &st = c->surf[0];
+        n = st.n; nPaths = st.nPaths;
+        dP = st.p; dWo = st.wo; dAlpha = st.alpha;
+        hp.resize(3 * (size_t)n);
+        if (n && !ok(hipMemcpy(hp.data(), dP, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost))) return PVOL_E_NO_DEVICE;
+        p = hp.data();
+    } else if (n) {
+        if (!p || !wo || !alpha) return PVOL_E_INVALID;
+        const size_t nb[3] = {sizeof(float) * 3 * (size_t)n, sizeof(float) * 3 * (size_t)n, sizeof(float) * 30 * (size_t)n};
+        const float *src[3] = {p, wo, alpha};
+        for (int i = 0; i < 3; ++i) {
+            if (!ok(hipMalloc(&up[i], nb[i]))) { drop(); return PVOL_E_NO_MEMORY; }
+            if (!ok(hipMemcpy(up[i], src[i], nb[i], hipMemcpyHostToDevice))) { drop(); return PVOL_E_NO_DEVICE; }
+        }
+        dP = up[0]; dWo = up[1]; dAlpha = up[2];
+    }
+    if (n && nPaths == 0) { drop(); return PVOL_E_INVALID; }
+    hipDeviceSynchronize();
+    pvol_free_caustic_map(c);
+    DevSurface &sf = c->hs.surf;
+    sf.enabled = 1; sf.nLookup = sp->n_used; sf.maxSpecularDepth = sp->max_specular_depth; sf.nCausticPaths = (int32_t)nPaths;
+    sf.maxDistSq = sp->max_dist * sp->max_dist;   // photonmap.cpp:345-346
+    sf.nPhotons = 0;
+    if (n) {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < n; ++i)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[3 * i + a]); hi[a] = std::max(hi[a], p[3 * i + a]); }
+        double cell = 0.5 * sp->max_dist, ext[3];
+        for (int a = 0; a < 3; ++a) ext[a] = std::max((double)hi[a] - lo[a], 1e-3 * sp->max_dist);
+        for (;;) {
+            double cells = 1;
+            for (int a = 0; a < 3; ++a) cells *= floor(ext[a] / cell) + 1;
+            if (cells <= 16777216.0) break;
+            cell *= 1.26;
+        }
+        sf.cellSize = (float)cell; sf.invCell = 1.f / sf.cellSize;
+        size_t ncells = 1;
+        for (int a = 0; a < 3; ++a) { sf.gridLo[a] = lo[a]; sf.gdim[a] = (int)floor(ext[a] / cell) + 1; ncells *= (size_t)sf.gdim[a]; }
+        bool good = ok(hipMalloc(&c->dCPos4, sizeof(float4) * (size_t)n)) && ok(hipMalloc(&c->dCAlpha4, sizeof(float4) * 8 * (size_t)n)) &&
+                    ok(hipMalloc(&c->dCWi4, sizeof(float4) * (size_t)n)) && ok(hipMalloc(&c->dCCellStart, sizeof(uint32_t) * (ncells + 1)));
+        if (!good) { drop(); pvol_free_caustic_map(c); pvol_push_scene(c); return PVOL_E_NO_MEMORY; }
+        GridBuildArgs g;
+        memset(&g, 0, sizeof(g));
+        g.p = dP; g.wi = dWo; g.alpha = dAlpha; g.n = n;
+        for (int a = 0; a < 3; ++a) { g.lo[a] = sf.gridLo[a]; g.gdim[a] = sf.gdim[a]; }
+        g.inv = sf.invCell;
+        g.volKind = PVOL_VOLUME_GRID;   // no Inside() filter: surface photons count wherever they lie
+        good = ok(pvol_build_grid(&g, c->dCPos4, c->dCAlpha4, c->dCWi4, c->dCCellStart, 0));
+        if (!good) { drop(); pvol_free_caustic_map(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
+        sf.nPhotons = n; sf.cellStart = c->dCCellStart; sf.pos4 = c->dCPos4; sf.alpha4 = c->dCAlpha4; sf.wi4 = c->dCWi4;
+    }
+    drop();
+    return pvol_push_scene(c);
 }
 
 int pvol_photon_count(pvol_ctx *c, uint32_t *n) {
@@ -464,6 +555,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     a.out = dOut; a.draws = dDraws; a.initState = dInit; a.finalState = dFinal; a.counters = c->dCounters;
     a.transmittanceOnly = transOnly;
     a.chunkCounter = c->dWords; a.needSeq = c->dWords + 1; a.gated = 0;
+    a.tauOut = c->dTauNext;   // render driver with the surface integrator on: li_group_kernel also reports the optical length
     // li_group_kernel bucket radius^2 = this x the guessed k-th distance^2 (measured at 64 spp: 1.3 55.5, 1.2 57.5, 1.12 58.0,
     // 1.06 56.6, 1.0 51.0 Msamples/s)
     { const char *gs = getenv("PVOL_GROUP_GUESS"); a.grpGuess = gs ? (float)atof(gs) : 1.15f; if (!(a.grpGuess >= 1.f)) a.grpGuess = 1.15f; }
@@ -530,6 +622,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         // homogeneous isotropic medium with a photon map and k <= 64: one ray per lane, gathers of 64 rays share a bucket
         const bool group = !c->noGroup && c->hs.volKind == PVOL_VOLUME_HOMOGENEOUS && c->hs.g == 0.f && c->hs.nPhotons > 0 &&
                            c->hs.nUsed >= 10 && c->hs.nUsed <= 64 && c->hs.candCap <= 4 * 64;
+        if (a.tauOut && !group) return PVOL_E_UNSUPPORTED;
         if (group) {
             unsigned long long gchunks = ((unsigned long long)nRays + 511ull) / 512ull;   // GRP_CH rays per chunk
             uint32_t gWaves = (uint32_t)std::min<unsigned long long>(gchunks, (unsigned long long)c->nCU * (unsigned long long)c->groupWavesPerCU);
@@ -554,6 +647,8 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             a.gated = 1;
             e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
         }
+    } else if (a.tauOut) {
+        return PVOL_E_UNSUPPORTED;
     } else if (sliced) {
         c->lastKernel = "li_replay_kernel";
         e = hipSuccess;

@@ -34,6 +34,20 @@ struct DevTri {
     float p1[3], p2[3], p3[3];
 };
 
+// PhotonIntegrator (integrators/photonmap.cpp), matte subset: parameters + the caustic photon map (same grid layout as the
+// volume map; alpha rows are the photons' raw weights, divided by nCausticPaths at lookup as photonmap.cpp:89 does)
+struct DevSurface {
+    int32_t enabled, nLookup, maxSpecularDepth, nCausticPaths;
+    float maxDistSq;
+    uint32_t nPhotons;
+    float gridLo[3];
+    float cellSize, invCell;
+    int32_t gdim[3];
+    const uint32_t *cellStart;
+    const float4 *pos4, *alpha4, *wi4;
+};
+struct DevShootScene;
+
 struct DevScene {
     // volume
     int32_t volKind;
@@ -67,6 +81,8 @@ struct DevScene {
     int32_t candCap;          // candidate list capacity (multiple of 64, >= nUsed + 128)
     int32_t maxSteps;         // upper bound of march steps per ray (lightNum array length)
     float rkEstimate;         // k-th nearest distance^2 expected at the map's mean density (first guess of a cold lookup)
+    DevSurface surf;                  // surface integrator, disabled unless pvol_set_surface_integrator enabled it
+    const DevShootScene *shootScene;  // materials of the triangles (device copy of the shooter's scene)
 };
 
 // One lookup li_group_kernel hands to li_fixup_kernel (pvol_group_dev.h)
@@ -106,6 +122,17 @@ struct DevCounters {
     unsigned long long nRays, nSteps, nTested, nKept, nLookupsLt10, nShadowUnoccluded, nErrors, pad;
     unsigned long long cySearch, cySelect, cyFlux, cyTotal;  // s_memtime cycles summed over waves (stats build only)
     unsigned long long diag[6];   // li_group_kernel (stats build): lookups whose radius guess failed / whose bucket plan was skipped / cycles spent in the exact fallback lookups
+};
+
+// surface_kernel (pvol_surface_dev.h)
+struct SurfArgs {
+    const DevScene *scene;
+    const pvol_ray *rays;
+    uint32_t nRays;
+    float *out;            // per ray X, Y, Z, T.y of the volume term: the surface term is ADDED to X, Y, Z
+    const float *tau;      // per ray: optical length of the last march step (T = exp(-sigma_t * tau))
+    float *surfOut;        // optional: the surface integrator's Li as X, Y, Z (3 floats per ray)
+    DevCounters *counters;
 };
 
 // Tile driver (pvol_tile_dev.h, pvol_tile.hip): what a SamplerRendererTask needs besides the scene.

@@ -75,9 +75,27 @@ __device__ float grid_tau_lane(const DevScene &S, V3 o, V3 d, float mint, float 
     return dsum * stepSize;
 }
 
-// Photons within Rs of c -> LDS bucket.  Returns the count, or -1 if the bucket would overflow.
-__device__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
-    float *bX = bucket, *bY = bucket + GRP_PITCH, *bZ = bucket + 2 * GRP_PITCH, *bI = bucket + 3 * GRP_PITCH;
+// A photon grid as the staging code sees it (the volume map of DevScene, or the caustic map of DevSurface)
+struct GridView {
+    float cellSize, invCell;
+    float gridLo[3];
+    int32_t gdim[3];
+    const uint32_t *cellStart;
+    const float4 *pos4;
+};
+__device__ __forceinline__ GridView volume_grid(const DevScene &S) {
+    GridView g;
+    g.cellSize = S.cellSize; g.invCell = S.invCell;
+    for (int i = 0; i < 3; ++i) { g.gridLo[i] = S.gridLo[i]; g.gdim[i] = S.gdim[i]; }
+    g.cellStart = S.cellStart; g.pos4 = S.pos4;
+    return g;
+}
+
+// Photons within Rs of c -> LDS bucket of CAP slots (SoA, pitch CAP + 4).  Returns the count, or -1 if the bucket would overflow.
+template <int CAP>
+__device__ int stage_bucket_g(const GridView &S, Gather &G, float *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
+    constexpr int GRP_PITCH_ = CAP + 4;
+    float *bX = bucket, *bY = bucket + GRP_PITCH_, *bZ = bucket + 2 * GRP_PITCH_, *bI = bucket + 3 * GRP_PITCH_;
     const float cell = S.cellSize, inv = S.invCell;
     const float eps = cell * 1e-4f;
     const float T = Rs * Rs;
@@ -157,7 +175,7 @@ __device__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, f
                     uint64_t m = __ballot(acc);
                     if (m) {
                         const int add = __popcll(m);
-                        if (count + add > GRP_CAP) return -1;
+                        if (count + add > CAP) return -1;
                         if (acc) {
                             const int at = count + (int)lanes_below(m, lane);
                             bX[at] = P[k].x; bY[at] = P[k].y; bZ[at] = P[k].z; bI[at] = __uint_as_float(I[k]);
@@ -178,6 +196,10 @@ __device__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, f
     if (lane < 4) { bX[count + lane] = 3.0e18f; bY[count + lane] = 3.0e18f; bZ[count + lane] = 3.0e18f; bI[count + lane] = 0.f; }   // pad to a multiple of four: never inside any radius
     __syncthreads();
     return count;
+}
+__device__ __forceinline__ int stage_bucket(const DevScene &S, Gather &G, float *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
+    const GridView g = volume_grid(S);
+    return stage_bucket_g<GRP_CAP>(g, G, bucket, c, Rs, lane, tested);
 }
 
 typedef float nf4 __attribute__((ext_vector_type(4)));
@@ -836,6 +858,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         *reinterpret_cast<f4 *>(A.out + ri * 4) = make_float4(accX * scale, accY * scale, accZ * scale, ty * 300.f / (106.856895f * 30));
                     }
                     if (!REPLAY && A.draws) A.draws[ri] = draws;
+                    if (A.tauOut) A.tauOut[ri] = hit ? lenLast : 0.f;   // T = exp(-sigma_t * this): what the surface term is attenuated by
                 }
             }
             if (!REPLAY) {   // stream positions: one atomic per group when all its rays belong to one stream (the usual case)

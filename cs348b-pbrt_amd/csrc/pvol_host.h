@@ -31,6 +31,7 @@ struct LiArgs {
     DeferRec *defer;            // li_group_kernel: lookups handed to li_fixup_kernel
     uint32_t *deferCount;
     uint32_t deferCap;
+    float *tauOut;              // optional: per ray the optical length of Li()'s last march step (T = exp(-sigma_t * tau))
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
@@ -49,6 +50,7 @@ extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve
 extern "C" size_t pvol_group_lds_bytes(int candCap);
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
                                            int replay, hipStream_t stream);
+extern "C" hipError_t pvol_launch_surface(const SurfArgs *a, uint32_t nWaves, hipStream_t stream);
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused);
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
@@ -101,6 +103,12 @@ struct pvol_ctx {
     struct SurfStore { float *p = 0, *wo = 0, *alpha = 0; uint32_t n = 0, nPaths = 0; } surf[3];
     float *dRad = 0;       // radiance photons: [n][8] = p(3) n(3) material index, pad
     uint32_t nRad = 0;
+    // caustic map of the surface integrator (pvol_set_surface_integrator), same cell layout as the volume map
+    float4 *dCPos4 = 0, *dCAlpha4 = 0, *dCWi4 = 0;
+    uint32_t *dCCellStart = 0;
+    float *dTau = 0;       // per sample of a render batch: optical length the surface term is attenuated over
+    size_t tauBytes = 0;
+    float *dTauNext = 0;   // set by the render driver around pvol_launch_batch when the surface integrator is on
     double prepSeconds[2] = {0.0, 0.0};   // last pvol_preprocess: shooting (all rounds + merges), search-structure build
     // tile driver work buffers (grown on demand, pvol_tile.hip)
     void *dTile[6] = {0, 0, 0, 0, 0, 0};
@@ -118,6 +126,7 @@ extern "C" {
 int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions);
 void pvol_free_photons(pvol_ctx *c);
 void pvol_free_surface_stores(pvol_ctx *c);
+void pvol_free_caustic_map(pvol_ctx *c);
 int pvol_push_scene(pvol_ctx *c);
 }
 #endif

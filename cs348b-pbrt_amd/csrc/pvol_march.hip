@@ -349,6 +349,7 @@ struct LiArgs {
     DeferRec *defer;            // li_group_kernel: lookups handed to li_fixup_kernel
     uint32_t *deferCount;
     uint32_t deferCap;
+    float *tauOut;              // optional: per ray the optical length of Li()'s last march step (T = exp(-sigma_t * tau))
 };
 
 // PhotonVolumeIntegrator::Transmittance with sample == NULL (photonvolume.cpp:15-30)
@@ -1400,4 +1401,5 @@ extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve
 }
 
 #include "pvol_group_dev.h"
+#include "pvol_surface_dev.h"
 #include "pvol_tile_dev.h"

@@ -156,6 +156,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     uint32_t nCausticPaths = 0, nIndirectPaths = 0, nDirectPaths = 0;
     size_t nVolume = 0;
     bool abortTasks = false;
+    uint32_t stallRounds = 0;
     rc = PVOL_OK;
     auto unsuccessful = [](uint32_t needed, uint64_t found, uint32_t shot) { return (found < needed && (found == 0 || found < shot / 1024)); };   // photonshooter.cpp:37-39
     for (;;) {
@@ -291,6 +292,20 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
             if (!g3) { rc = PVOL_E_NO_DEVICE; break; }
         }
         if (rc == PVOL_E_LIMIT || rc == PVOL_E_NO_DEVICE) break;
+        // The reference has no exit for a store that stops growing after a good start (its `unsuccessful` test, photonshooter.cpp:37-39,
+        // passes once found >= 4): e.g. a matte scene whose "caustic" photons all come through the medium, after the volume map is
+        // full -- it would shoot forever.  Here 256 rounds in a row without a single photon for any store still wanted end the
+        // pass the way the reference's own abort does (stores erased, PVOL_E_SHOOT_FAILED).
+        if (!abortTasks) {
+            const bool progress = nCaustic != surfBefore[0] || nIndirect != surfBefore[2] || nVolume != volBefore;
+            stallRounds = progress ? 0u : stallRounds + 1u;
+            if (stallRounds >= 256u) {
+                nVolume = 0; nCaustic = nIndirect = 0; nRadTotal = 0;
+                for (uint32_t t = 0; t < T; ++t) flags[t] |= 8u;
+                abortTasks = true;
+                rc = PVOL_E_SHOOT_FAILED;
+            }
+        }
     }
     // paths, follow_calls, no_hit, march_steps, interactions, absorbed, stored_volume, caustic, direct, indirect, split_children, nshot
     c->shootStats[0] = st[0]; c->shootStats[1] = st[1]; c->shootStats[2] = st[2]; c->shootStats[3] = st[3]; c->shootStats[4] = st[4];

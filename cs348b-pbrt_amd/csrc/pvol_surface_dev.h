@@ -1,0 +1,275 @@
+// pvol_surface_dev.h -- included by pvol_march.hip.  SURVEY 8(f)-2, the part of PhotonIntegrator::Li (integrators/
+// photonmap.cpp:154-319) that the BASELINE scenes' camera rays need on their matte walls:
+//   L = UniformSampleAllLights (core/integrator.cpp:47-79 -> EstimateDirect :117-174, delta lights)
+//     + LPhoton(causticMap)     (photonmap.cpp:62-108, diffuse branch: kernel-weighted k-NN estimate)
+// (`indirectphotons 0` in both scenes leaves the final gather and the indirect estimate without a map), plus every RNG
+// draw of the rest of that Li(): 2 x 72 of BSDF::rho inside LPhoton, 2 x 3 of the BSDFSample(rng) that SpecularReflect /
+// SpecularTransmit construct, one per unoccluded light sample (visibility.Transmittance(..., NULL, rng)).  None of the drawn
+// VALUES reaches the result on a Lambertian surface in an analytic medium, so the draws are COUNTED by the tile pre-pass
+// (they precede the sample's volume Li() in the task's stream) and the radiance is added by surface_kernel afterwards:
+//   sample = T * Lsurface + Lvi        (SamplerRenderer::Li, renderers/samplerrenderer.cpp:238-250)
+// Not covered (the host refuses such scenes when the surface integrator is on): specular BSDFs (the recursion of
+// SpecularReflect/Transmit), an indirect map / final gather, VolumeGrid media (the shadow-ray tau() offset is a drawn value).
+#define SRF_CAP 2048   // caustic bucket capacity (photons within maxdist + spread of a group's hit points)
+
+struct SurfHit {
+    int tri;
+    float t;
+    V3 p, nn;
+};
+// Scene::Intersect for one lane: closest hit, the later triangle on equal t (as the linear scans of this library and its oracle),
+// DifferentialGeometry normal as shapes/trianglemesh.cpp:163-181 + core/diffgeom.cpp:46-54 build it
+__device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit *h) {
+    float mt = INFINITY;
+    int best = -1;
+    for (int i = 0; i < S.nTris; ++i) {
+        float t;
+        if (tri_closest(S.tris[i], o, d, mint, mt, &t)) { mt = t; best = i; }
+    }
+    if (best < 0) return false;
+    const DevTri &tr = S.tris[best];
+    const V3 p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]), p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+    const float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
+    const V3 dp1 = p1 - p3, dp2 = p2 - p3;
+    const float invdet = 1.f / (du1 * dv2 - dv1 * du2);
+    const V3 dpdu = (dp1 * dv2 - dp2 * dv1) * invdet;
+    const V3 dpdv = (dp1 * (-du2) + dp2 * du1) * invdet;
+    h->tri = best;
+    h->t = mt;
+    h->p = o + d * mt;
+    h->nn = normalize(cross(dpdu, dpdv));
+    if (S.shootScene->triFlip[best]) h->nn = h->nn * -1.f;
+    return true;
+}
+
+// One delta light seen from a surface point: Light::Sample_L(p, eps, ...) (spot.cpp:50-57, point.cpp:50-57, distant.cpp:48-55),
+// the shadow ray of its VisibilityTester (core/light.h:85-101) and whether EstimateDirect would take the sample.
+struct SurfLight { bool take; V3 wi; float scale; RayD vis; };   // radiance = intensity * scale
+__device__ __forceinline__ SurfLight surf_light(const DevScene &S, int ln, V3 p, float eps, V3 n, V3 wo, bool lambert, unsigned blackMask) {
+    SurfLight r;
+    const DevLight &light = S.lights[ln];
+    r.scale = 1.f;
+    if (light.kind == PVOL_LIGHT_DISTANT) {
+        r.wi = v3(light.dir[0], light.dir[1], light.dir[2]);
+        r.vis.o = p; r.vis.d = r.wi; r.vis.mint = eps; r.vis.maxt = INFINITY;
+    } else {
+        const V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
+        r.wi = normalize(lp - p);
+        const float dist = len(p - lp);
+        r.vis.o = p; r.vis.d = vdiv(lp - p, dist); r.vis.mint = eps; r.vis.maxt = dist * (1.f - 0.f);
+        const float d2 = len_sq(lp - p);
+        float fall = 1.f;
+        if (light.kind == PVOL_LIGHT_SPOT) {
+            const V3 w = -r.wi;
+            const V3 wl = normalize(v3(light.w2l[0] * w.x + light.w2l[1] * w.y + light.w2l[2] * w.z, light.w2l[4] * w.x + light.w2l[5] * w.y + light.w2l[6] * w.z,
+                                       light.w2l[8] * w.x + light.w2l[9] * w.y + light.w2l[10] * w.z));
+            const float ct = wl.z;
+            if (ct < light.cosTotalWidth) fall = 0.f;
+            else if (!(ct > light.cosFalloffStart)) {
+                const float delta = (ct - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+                fall = delta * delta * delta * delta;
+            }
+        }
+        r.scale = fall / d2;
+    }
+    const bool liBlack = r.scale == 0.f || ((blackMask >> ln) & 1u);
+    // BSDF::f: the Lambertian lobe counts only when wi and wo lie on the same side of the geometric normal (reflection.cpp:627-644)
+    const bool fOk = lambert && dot(r.wi, n) * dot(wo, n) > 0.f;
+    r.take = !liBlack && fOk && !lane_occluded(S, r.vis);
+    return r;
+}
+
+// RandomUInt calls of PhotonIntegrator::Li for a camera ray that hit triangle h (in front of the sample's volume Li())
+__device__ uint32_t surf_count_draws(const DevScene &S, const SurfHit &h, V3 d, unsigned blackMask) {
+    const DevMaterial &m = S.shootScene->mats[S.shootScene->triMat[h.tri]];
+    const bool lambert = m.kind == PVOL_MATERIAL_MATTE && m.nBxdf > 0;   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd
+    const V3 wo = -d;
+    uint32_t n = 0;
+    for (int ln = 0; ln < S.nLights; ++ln) n += surf_light(S, ln, h.p, 1e-3f * h.t, h.nn, wo, lambert, blackMask).take ? 1u : 0u;
+    if (S.surf.nPhotons > 0u && lambert) n += 144u;     // LPhoton(causticMap): two BSDF::rho(wo, rng)
+    if (0 + 1 < S.surf.maxSpecularDepth) n += 6u;       // SpecularReflect + SpecularTransmit: BSDFSample(rng) each
+    return n;
+}
+
+
+// One camera sample per lane, 64 consecutive samples (one pixel's, at >= 64 spp) per group: their hit points lie within a
+// pixel footprint, so the caustic lookups share one LDS bucket of the photons within maxdist + spread of the group's centre.
+__global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    constexpr int PITCH = SRF_CAP + 4;
+    float *bucket = reinterpret_cast<float *>(lds);
+    Gather G;
+    G.cap = 0; G.cd = 0; G.ci = 0;
+    G.paint = reinterpret_cast<uint32_t *>(bucket + 4 * PITCH);
+    const float *bX = bucket, *bY = bucket + PITCH, *bZ = bucket + 2 * PITCH, *bI = bucket + 3 * PITCH;
+    unsigned blackMask = 0u;
+    { const int q = lane & 7; for (int l = 0; l < S.nLights; ++l) if (spec_is_black(ld4(S.lights[l].intensity, q))) blackMask |= 1u << l; }
+    GridView cg;
+    cg.cellSize = S.surf.cellSize; cg.invCell = S.surf.invCell;
+    for (int i = 0; i < 3; ++i) { cg.gridLo[i] = S.surf.gridLo[i]; cg.gdim[i] = S.surf.gdim[i]; }
+    cg.cellStart = S.surf.cellStart; cg.pos4 = S.surf.pos4;
+    const int k = S.surf.nLookup;
+    for (unsigned long long g0 = (unsigned long long)blockIdx.x * LANES; g0 < A.nRays; g0 += (unsigned long long)gridDim.x * LANES) {
+        const size_t ri = (size_t)g0 + lane;
+        const bool have = ri < A.nRays;
+        const pvol_ray pr = A.rays[have ? ri : 0];
+        const V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
+        SurfHit h;
+        h.tri = 0; h.t = 0.f; h.p = h.nn = v3(0.f, 0.f, 0.f);
+        const bool hit = have && surf_closest(S, o, d, pr.mint, &h);   // the ray's maxt is this very t (the tile pre-pass clipped it)
+        float Ls[32];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) Ls[b] = 0.f;
+        const DevMaterial &mat = S.shootScene->mats[S.shootScene->triMat[h.tri]];
+        const bool lambert = hit && mat.kind == PVOL_MATERIAL_MATTE && mat.nBxdf > 0;
+        const V3 wo = -d;
+        // ---- direct lighting: Ld = f * Li * (AbsDot(wi, n) / pdf), Li = light radiance * Transmittance of the shadow ray
+        if (lambert) {
+            for (int ln = 0; ln < S.nLights; ++ln) {
+                const SurfLight sl = surf_light(S, ln, h.p, 1e-3f * h.t, h.nn, wo, true, blackMask);
+                if (!sl.take) continue;
+                float lenAB = 0.f;   // tau of the analytic medium along the shadow ray (homogeneous.h:80-84)
+                if (S.volKind != PVOL_VOLUME_NONE) {
+                    float t0, t1;
+                    if (vol_intersect(S, sl.vis, &t0, &t1)) { const V3 a = sl.vis.o + sl.vis.d * t0, b = sl.vis.o + sl.vis.d * t1; lenAB = len(a - b); }
+                }
+                const float geo = fabsf(dot(sl.wi, h.nn)) / 1.f;
+                const float kSh = -1.442695041f * lenAB;
+#pragma unroll
+                for (int b = 0; b < 30; ++b) {
+                    const float sT = S.sigA[b] + S.sigS[b];
+                    const float Li = (S.lights[ln].intensity[b] * sl.scale) * __builtin_amdgcn_exp2f(sT * kSh);
+                    Ls[b] += (mat.kd[b] * 0.31830988618379067154f) * Li * geo;
+                }
+            }
+        }
+        // ---- caustic estimate (photonmap.cpp:62-108), shared buckets: the samples still waiting are served cluster by cluster
+        // -- all of them at once when they lie within maxdist of their common centre (one pixel's samples on one wall), else
+        // those within maxdist of the first waiting sample's hit point, and that sample alone if even this bucket overflows.
+        const bool needAny = lambert && S.surf.nPhotons > 0u;
+        unsigned long long pending = __ballot(needAny);
+        const float maxDist = sqrtf(S.surf.maxDistSq);
+        bool alone = false;
+        while (pending) {
+            const bool waiting = ((pending >> lane) & 1ull) != 0ull;
+            const float big = 3.0e38f;
+            float lx = waiting ? h.p.x : big, ly = waiting ? h.p.y : big, lz = waiting ? h.p.z : big;
+            float hx = waiting ? h.p.x : -big, hy = waiting ? h.p.y : -big, hz = waiting ? h.p.z : -big;
+            lx = -wave_max(-lx); ly = -wave_max(-ly); lz = -wave_max(-lz);
+            hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+            V3 c = v3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
+            float rho = wave_max(waiting ? len(h.p - c) : 0.f);
+            bool need = waiting;
+            if (alone || rho > maxDist) {
+                const int piv = __ffsll((long long)pending) - 1;
+                c = v3(lane_f(h.p.x, piv), lane_f(h.p.y, piv), lane_f(h.p.z, piv));
+                const float dPiv = len(h.p - c);
+                need = waiting && (alone ? dPiv == 0.f : dPiv <= maxDist);
+                rho = alone ? 0.f : maxDist;
+            }
+            const float Rs = (maxDist + rho) * 1.0001f + 1e-6f;
+            unsigned long long tst = 0;
+            __syncthreads();
+            const int Mb = stage_bucket_g<SRF_CAP>(cg, G, bucket, c, Rs, lane, tst);
+            if (Mb < 0 && !alone) { alone = true; continue; }   // retry with the first waiting sample on its own
+            pending &= ~__ballot(need);
+            alone = false;
+            if (Mb < 0) {   // more photons within maxdist of ONE point than the bucket holds: reported, never guessed
+                if (lane == 0) atomicAdd(&A.counters->nErrors, 1ull);
+            } else {
+                // pass A: how many photons lie inside maxdist (kdtree.h:180: dist2 < maxDistSquared), and -- when that is at least
+                // nused -- the nused-th smallest distance^2 by bisection over the fp32 bit pattern (the heap of PhotonProcess keeps
+                // the nused nearest and leaves maxDistSquared at the farthest of them)
+                int nIn = 0;
+                for (int i = 0; i < Mb; ++i) {
+                    const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                    nIn += (need && dx * dx + dy * dy + dz * dz < S.surf.maxDistSq) ? 1 : 0;
+                }
+                float r2 = S.surf.maxDistSq;
+                uint32_t kth = 0xffffffffu;   // members: d2 < maxDistSq when fewer than nused lie inside, else the nused nearest
+                int tieQuota = 0;
+                if (__ballot(nIn >= k)) {
+                    uint32_t lo = 0u, hi = __float_as_uint(S.surf.maxDistSq);
+                    const bool sel = nIn >= k;
+                    while (__ballot(sel && lo < hi)) {   // smallest bit pattern v with count(d2 <= v) >= k
+                        const uint32_t mid = lo + ((hi - lo) >> 1);
+                        int cnt = 0;
+                        for (int i = 0; i < Mb; ++i) {
+                            const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                            cnt += (__float_as_uint(dx * dx + dy * dy + dz * dz) <= mid) ? 1 : 0;
+                        }
+                        if (sel && lo < hi) { if (cnt >= k) hi = mid; else lo = mid + 1u; }
+                    }
+                    if (sel) {
+                        kth = lo;
+                        r2 = __uint_as_float(lo);
+                        int less = 0;
+                        for (int i = 0; i < Mb; ++i) {
+                            const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                            less += (__float_as_uint(dx * dx + dy * dy + dz * dz) < kth) ? 1 : 0;
+                        }
+                        tieQuota = k - less;   // photons AT the k-th distance^2 that still belong (bucket order)
+                    }
+                }
+                // pass B: Lr = sum over members on the wo side of  kernel / (nPaths r^2) * alpha   (the -wo side carries rho_t == 0)
+                const V3 Nf = dot(h.nn, wo) < 0.f ? h.nn * -1.f : h.nn;
+                const float norm = 1.f / ((float)S.surf.nCausticPaths * r2);
+                float acc[32];
+#pragma unroll
+                for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+                typedef const __attribute__((address_space(4))) nf4 cf4;
+                for (int i = 0; i < Mb; ++i) {
+                    const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    bool mem = need && d2 < S.surf.maxDistSq;
+                    if (kth != 0xffffffffu) {
+                        const uint32_t bits = __float_as_uint(d2);
+                        mem = need && bits < kth;
+                        if (need && bits == kth && tieQuota > 0) { mem = true; --tieQuota; }
+                    }
+                    const uint32_t pidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[i]));
+                    const f4 wi4 = S.surf.wi4[pidx];
+                    const float sW = 1.f - d2 / r2;
+                    float wgt = (3.f * 0.31830988618379067154f * sW * sW) * norm;
+                    if (!mem || !(Nf.x * wi4.x + Nf.y * wi4.y + Nf.z * wi4.z > 0.f)) wgt = 0.f;
+                    if (!__ballot(wgt != 0.f)) continue;
+                    cf4 *row = (cf4 *)(S.surf.alpha4 + (size_t)pidx * 8);
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const nf4 rr = row[qq];
+                        acc[4 * qq] = __builtin_fmaf(rr.x, wgt, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rr.y, wgt, acc[4 * qq + 1]);
+                        acc[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, acc[4 * qq + 3]);
+                    }
+                }
+#pragma unroll
+                for (int b = 0; b < 30; ++b) Ls[b] += acc[b] * mat.kd[b] * 0.31830988618379067154f;   // Lr * rho(wo) * INV_PI, rho == Kd
+            }
+        }
+        // ---- compose: sample = T * Lsurface + Lvi
+        if (hit) {
+            const float kT = -1.442695041f * A.tau[ri];
+            float x = 0.f, y = 0.f, z = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+            for (int b = 0; b < 30; ++b) {
+                const float Tb = __builtin_amdgcn_exp2f((S.sigA[b] + S.sigS[b]) * kT);
+                const float v = Tb * Ls[b];
+                x += S.cieX[b] * v; y += S.cieY[b] * v; z += S.cieZ[b] * v;
+                sx += S.cieX[b] * Ls[b]; sy += S.cieY[b] * Ls[b]; sz += S.cieZ[b] * Ls[b];
+            }
+            const float scale = float(700 - 400) / float(106.856895f * 30);
+            float *op = A.out + ri * 4;
+            op[0] += x * scale; op[1] += y * scale; op[2] += z * scale;
+            if (A.surfOut) { A.surfOut[3 * ri] = sx * scale; A.surfOut[3 * ri + 1] = sy * scale; A.surfOut[3 * ri + 2] = sz * scale; }
+        } else if (have && A.surfOut) {
+            A.surfOut[3 * ri] = 0.f; A.surfOut[3 * ri + 1] = 0.f; A.surfOut[3 * ri + 2] = 0.f;
+        }
+    }
+}
+
+extern "C" hipError_t pvol_launch_surface(const SurfArgs *a, uint32_t nWaves, hipStream_t stream) {
+    const size_t ldsBytes = (size_t)(SRF_CAP + 4) * 16 + PAINT_CAP * 4;
+    hipLaunchKernelGGL(surface_kernel, dim3(nWaves), dim3(LANES), ldsBytes, stream, *a);
+    return hipGetLastError();
+}

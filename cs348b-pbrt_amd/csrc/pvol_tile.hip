@@ -271,9 +271,31 @@ extern "C" int pvol_render_tasks_device(pvol_ctx *c, const pvol_camera *camera, 
             return PVOL_E_NO_DEVICE;
         if (!ok(hipStreamSynchronize(stream))) return PVOL_E_NO_DEVICE;   // hs / win are host temporaries
         T.windows = dWin; T.rays = dRays; T.xy = dXY;
+        const bool surfOn = c->hs.surf.enabled != 0;
+        if (surfOn && nRays) {
+            const size_t want = 4 * nRays;
+            if (want > c->tauBytes) {
+                hipStreamSynchronize(stream);
+                if (c->dTau) hipFree(c->dTau);
+                c->dTau = 0; c->tauBytes = 0;
+                if (!ok(hipMalloc(&c->dTau, want))) return PVOL_E_NO_MEMORY;
+                c->tauBytes = want;
+            }
+        }
         if (nRays) {
+            c->dTauNext = surfOn ? c->dTau : 0;
             int rc = pvol_launch_batch(c, dRays, (uint32_t)nRays, dStreams, nStreams, PVOL_OUT_XYZ, dOut, 0, 0, 0, 0, maxRays, &T, stream);
+            c->dTauNext = 0;
             if (rc != PVOL_OK) return rc;
+            if (surfOn) {   // Ls of PhotonIntegrator::Li, composed as T * Ls + Lvi (samplerrenderer.cpp:95-97)
+                SurfArgs sa;
+                sa.scene = c->ds; sa.rays = dRays; sa.nRays = (uint32_t)nRays; sa.out = dOut; sa.tau = c->dTau;
+                sa.surfOut = debug ? debug->d_surf_xyz ? debug->d_surf_xyz + 3 * doneRays : 0 : 0;
+                sa.counters = c->dCounters;
+                const unsigned long long groups = (nRays + 63) / 64;
+                if (!ok(pvol_launch_surface(&sa, (uint32_t)std::min<unsigned long long>(groups, (unsigned long long)c->nCU * 24ull), stream)))
+                    return PVOL_E_NO_DEVICE;
+            }
             rc = film_add(c, film, dXY, dOut, 4, nRays, 1, dPixels, stream);
             if (rc != PVOL_OK) return rc;
         }

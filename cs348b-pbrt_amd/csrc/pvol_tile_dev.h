@@ -274,6 +274,9 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
     const int q = lane & 7;
     const bool blackS = spec_is_black(ld4(S.sigS, q));
     const bool lightBlack = S.nLights > 0 ? spec_is_black(ld4(S.lights[0].intensity, q)) : true;
+    unsigned blackMask = 0u;   // per light, for the surface integrator's direct lighting
+    for (int l = 0; l < S.nLights; ++l) if (spec_is_black(ld4(S.lights[l].intensity, q))) blackMask |= 1u << l;
+    const bool surfOn = !FUSED && S.surf.enabled != 0;
     pvol_ray *rays = T.rays;
     const CountConsts CC = count_consts(S);
     for (uint32_t k = begin; k < end; k += T.spp) {
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
             float imageX = 0.f, imageY = 0.f, tm = 0.f, su = 0.f, maxt = INFINITY;
             V3 o = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 1.f);
             const size_t ri = (size_t)st.first_ray + k + i;
+            uint32_t surfDraws = 0u;   // what PhotonIntegrator::Li draws in front of this sample's volume Li() (pvol_surface_dev.h)
             if (on) {
                 imageX = xPos + L.image[2 * i];
                 imageY = yPos + L.image[2 * i + 1];
@@ -296,10 +300,14 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
                 su = L.scatter[i];
                 tile_camera_ray(T, imageX, imageY, &o, &d);
                 maxt = tile_clip(ltri, S.nTris, o, d);
+                if (surfOn && maxt < INFINITY) {
+                    SurfHit sh;
+                    if (surf_closest(S, o, d, 0.f, &sh)) surfDraws = surf_count_draws(S, sh, d, blackMask);
+                }
                 pvol_ray pr;
                 pr.o[0] = o.x; pr.o[1] = o.y; pr.o[2] = o.z; pr.mint = 0.f;
                 pr.d[0] = d.x; pr.d[1] = d.y; pr.d[2] = d.z; pr.maxt = maxt;
-                pr.time = tm; pr.scatter_u = su; pr.rng_skip = (i == 0) ? samplerDraws : 0u; pr.flags = 0u;
+                pr.time = tm; pr.scatter_u = su; pr.rng_skip = ((i == 0) ? samplerDraws : 0u) + surfDraws; pr.flags = 0u;
                 rays[ri] = pr;
                 T.xy[2 * ri] = imageX;
                 T.xy[2 * ri + 1] = imageY;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
             if (!FUSED) {
                 uint32_t nd = (on && !(T.debugSkip & 2u)) ? tile_count_draws(S, CC, ltri, trows, o, d, maxt, su, blackS, lightBlack, T.debugSkip) : ((T.debugSkip & 2u) ? 270u : 0u);
                 // wave total (integer adds in any order are exact)
-                unsigned long long tot = nd;
+                unsigned long long tot = nd + surfDraws;
                 for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
                 if (!(T.debugSkip & 4u)) rng_skip<true>(rng, tot, lane);
             } else {

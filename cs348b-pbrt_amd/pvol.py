@@ -64,6 +64,7 @@ def lib():
         L.pvol_download_surface_photons.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_uint32]
         L.pvol_radiance_photon_count.argtypes = [C.c_void_p, _u32p]
         L.pvol_download_radiance_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, C.c_uint32]
+        L.pvol_set_surface_integrator.argtypes = [C.c_void_p, C.POINTER(abi.SurfaceParams), _f32p, _f32p, _f32p, C.c_uint32]
         L.pvol_march_kernel_name.restype = C.c_char_p
         L.pvol_gaussian_filter_table.argtypes = [C.c_float, C.c_float, C.c_float, _f32p]
         L.pvol_gaussian_filter_table.restype = None
@@ -85,7 +86,8 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats",
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
            "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_surface_photon_count",
-           "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons"]
+           "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons",
+           "pvol_set_surface_integrator"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -204,6 +206,26 @@ class PhotonVolume:
         ids = np.ascontiguousarray(task_ids, np.uint32)
         _check(lib().pvol_render_tasks_device(self._h, C.byref(camera), C.byref(film), C.byref(sampler), ids.ctypes.data_as(_u32p), len(ids),
                                               d_pixels, C.byref(debug) if debug is not None else None, hip_stream), "pvol_render_tasks_device")
+
+    def set_surface_integrator(self, n_used=50, max_dist=0.1, max_specular_depth=5, final_gather=False, caustic=None, n_paths=0,
+                               from_preprocess=False, off=False):
+        """PhotonIntegrator in front of the volume term (CreatePhotonMapSurfaceIntegrator, photonmap.cpp:336-363: nused 50,
+        maxdist .1, maxspeculardepth 5).  `caustic` = (p[n,3], wo[n,3], alpha[n,30]) with `n_paths`, or from_preprocess=True to
+        take the caustic photons the last preprocess() kept; off=True disables."""
+        if off:
+            _check(lib().pvol_set_surface_integrator(self._h, None, None, None, None, 0), "pvol_set_surface_integrator")
+            return
+        sp = abi.SurfaceParams()
+        sp.n_used, sp.max_dist, sp.max_specular_depth, sp.final_gather = int(n_used), float(max_dist), int(max_specular_depth), int(bool(final_gather))
+        sp.n_caustic_paths, sp.use_preprocess_store = int(n_paths), int(bool(from_preprocess))
+        if caustic is None or from_preprocess:
+            _check(lib().pvol_set_surface_integrator(self._h, C.byref(sp), None, None, None, 0), "pvol_set_surface_integrator")
+            return
+        p, w, a = (np.ascontiguousarray(x, np.float32) for x in caustic)
+        n = p.size // 3
+        assert w.size == 3 * n and a.size == 30 * n
+        _check(lib().pvol_set_surface_integrator(self._h, C.byref(sp), p.ctypes.data_as(_f32p), w.ctypes.data_as(_f32p), a.ctypes.data_as(_f32p), n),
+               "pvol_set_surface_integrator")
 
     def film_add_samples(self, film, d_image_xy, d_xyz, stride, n, d_pixels, hip_stream=0):
         _check(lib().pvol_film_add_samples_device(self._h, C.byref(film), d_image_xy, d_xyz, stride, n, d_pixels, hip_stream),

@@ -31,7 +31,7 @@ extern "C" {
 
 #define PVOL_NBINS 30
 #define PVOL_MT_N 624
-#define PVOL_ABI_VERSION 1
+#define PVOL_ABI_VERSION 2
 
 typedef enum pvol_status {
     PVOL_OK = 0,
@@ -221,7 +221,25 @@ typedef struct pvol_render_debug {   /* optional DEVICE buffers that receive the
     float *d_image_xy;           /* 2 floats per sample: CameraSample::imageX, imageY              */
     float *d_xyz;                /* 4 floats per sample: Lvi as X,Y,Z and T.y()                    */
     pvol_stream *d_streams;      /* one per task of the call, end_draw filled                      */
+    float *d_surf_xyz;           /* 3 floats per sample: the surface integrator's Li as X,Y,Z      */
+                                 /* (only with pvol_set_surface_integrator enabled; may be NULL)   */
 } pvol_render_debug;
+
+/* Surface integrator in front of the volume term: PhotonIntegrator::Li
+ * (integrators/photonmap.cpp:154-319) for camera rays that end on MATTE surfaces, without an indirect
+ * map (`indirectphotons 0`, both BASELINE scenes): UniformSampleAllLights over delta lights
+ * (core/integrator.cpp:47-79, :117-174), the caustic estimate LPhoton (photonmap.cpp:62-108) and the
+ * RNG traffic of the rest of that Li() (2 x BSDF::rho, 2 x BSDFSample, one draw per unoccluded light). */
+typedef struct pvol_surface_params {
+    int32_t n_used;              /* "nused" (photonmap.cpp:340), lookup size of the caustic estimate */
+    float max_dist;              /* "maxdist" (photonmap.cpp:345)                                    */
+    int32_t max_specular_depth;  /* "maxspeculardepth" (photonmap.cpp:341): > 1 costs 6 draws per hit */
+    int32_t final_gather;        /* accepted for completeness: without an indirect map it changes nothing */
+    uint32_t n_caustic_paths;    /* nCausticPaths (photonshooter.cpp:215) of the map passed along    */
+    int32_t use_preprocess_store;/* 1: take the caustic photons (and path count) the last pvol_preprocess kept
+                                    (params.keep_surface_photons) instead of the arrays passed        */
+    uint32_t reserved[2];
+} pvol_surface_params;
 
 typedef struct pvol_ctx pvol_ctx;
 
@@ -354,6 +372,17 @@ uint64_t pvol_render_sample_count(const pvol_sampler *s, const uint32_t *task_id
 int pvol_render_tasks_device(pvol_ctx *ctx, const pvol_camera *camera, const pvol_film *film,
                              const pvol_sampler *sampler, const uint32_t *task_ids, uint32_t n_task_ids,
                              float *d_pixels, const pvol_render_debug *debug, void *hip_stream);
+
+/* Enables (sp != NULL) or disables (sp == NULL) the surface integrator for pvol_render_tasks_device:
+ * SamplerRendererTask::Run then computes Ls = surface Li, and the film receives T * Ls + Lvi
+ * (samplerrenderer.cpp:95-97,239-251).  p/wo/alpha: the caustic map's n photons (p 3, wo 3, alpha 30
+ * floats each; n == 0: no caustic map, as when the shooter stored no caustic photon).
+ * PVOL_E_UNSUPPORTED: a triangle of the scene carries a non-matte material (here), or the volume /
+ * nused lie outside li_group_kernel's domain (from pvol_render_tasks_device).  A
+ * lookup with more than 2048 caustic photons within maxdist of ONE hit point is counted as an error
+ * (pvol_check_errors), never truncated.  pvol_set_scene disables the surface integrator again. */
+int pvol_set_surface_integrator(pvol_ctx *ctx, const pvol_surface_params *sp, const float *p, const float *wo,
+                                const float *alpha, uint32_t n);
 
 /* ImageFilm::AddSample (film/image.cpp:78-137) for n samples: d_image_xy 2 floats, d_xyz `xyz_stride`
  * floats per sample (X,Y,Z first). */

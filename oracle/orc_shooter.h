@@ -369,6 +369,7 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
     uint32_t nshot = 0;
     uint64_t nCaustic = 0, nIndirect = 0, nDirect = 0;
     bool abortTasks = false;
+    uint32_t stallRounds = 0;
     int rc = 0;
     const uint32_t blockSize = 4096;
     auto unsuccessful = [](uint32_t needed, uint64_t found, uint32_t shot) {  // photonshooter.cpp:37-39
@@ -388,6 +389,7 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
             for (auto &x : th) x.join();
         }
         // merge in task order (photonshooter.cpp:280-351)
+        const uint64_t before[3] = {nCaustic, nIndirect, (uint64_t)volumeOut->size()};
         for (auto *t : live) {
             if (abortTasks) { t->finished = true; continue; }
             if (nshot > 500000 && (unsuccessful(params.n_caustic_photons, nCaustic, blockSize) ||
@@ -425,6 +427,18 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
                 if (volumeOut->size() >= params.n_volume_photons) t->volumeDone = true;
             }
             if (t->indirectDone && t->causticDone && t->volumeDone) t->finished = true;
+        }
+        // NOT in the reference (it would shoot forever): 256 rounds in a row without a photon for any store still wanted abort the
+        // pass like the test above does -- the same guard as the product's (pvol_shoot_host.hip), so that a test cannot hang
+        if (!abortTasks) {
+            const bool progress = nCaustic != before[0] || nIndirect != before[1] || volumeOut->size() != before[2];
+            stallRounds = progress ? 0u : stallRounds + 1u;
+            if (stallRounds >= 256u) {
+                volumeOut->clear(); nCaustic = nIndirect = 0;
+                if (surf) { surf->caustic.clear(); surf->indirect.clear(); surf->radiance.clear(); }
+                for (auto *t : tasks) t->finished = true;
+                abortTasks = true; rc = PVOL_E_SHOOT_FAILED;
+            }
         }
     }
     for (auto *t : tasks) {

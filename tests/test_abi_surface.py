@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(pvol):
     for n in names:
         assert hasattr(L, n), "libpvol.so does not export %s" % n
     assert sorted(pvol.EXPORTS) == names
-    assert L.pvol_abi_version() == 1
+    assert L.pvol_abi_version() == 2   # 2: pvol_render_debug.d_surf_xyz, pvol_set_surface_integrator
 
 
 def test_struct_sizes_match_the_header(pvol, tmp_path):

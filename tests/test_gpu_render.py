@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import RENDER_CASES, abi, load_photons, load_render_case, load_scene
+from conftest import RENDER_CASES, RENDER_SURF_CASES, abi, load_photons, load_render_case, load_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -224,3 +224,125 @@ def test_render_rejects_what_it_cannot_do(torch_cuda):
     finally:
         pv.close()
         _restore(old)
+
+
+# ---------------------------------------------------------------- surface integrator in front of the volume term
+def _render_surface(torch, pv, cam, film, smp, tasks, n):
+    dev = torch.device("cuda:0")
+    pixels = torch.zeros((film.y_resolution, film.x_resolution, 4), dtype=torch.float32, device=dev)
+    rays = torch.zeros((max(n, 1), 48), dtype=torch.uint8, device=dev)
+    xy = torch.zeros((max(n, 1), 2), dtype=torch.float32, device=dev)
+    xyz = torch.zeros((max(n, 1), 4), dtype=torch.float32, device=dev)
+    sxyz = torch.zeros((max(n, 1), 3), dtype=torch.float32, device=dev)
+    streams = torch.zeros((len(tasks), 32), dtype=torch.uint8, device=dev)
+    dbg = abi.RenderDebug(rays.data_ptr(), xy.data_ptr(), xyz.data_ptr(), streams.data_ptr(), sxyz.data_ptr())
+    pv.render_tasks(cam, film, smp, tasks, pixels.data_ptr(), dbg)
+    torch.cuda.synchronize()
+    pv.check_errors()
+    return {"pixels": pixels.cpu().numpy(), "rays": rays.cpu().numpy().view(abi.RAY_DTYPE).reshape(-1)[:n], "xy": xy.cpu().numpy()[:n],
+            "xyzT": xyz.cpu().numpy()[:n], "surf_xyz": sxyz.cpu().numpy()[:n], "streams": streams.cpu().numpy().view(abi.STREAM_DTYPE).reshape(-1)}
+
+
+def _rel_l2(got, ref):
+    got, ref = got.astype(np.float64), ref.astype(np.float64)
+    scale = max(np.abs(ref).max(), 1e-30)
+    return np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-4 * scale)
+
+
+@pytest.mark.parametrize("name", list(RENDER_SURF_CASES))
+def test_surface_integrator_matches_reference_capture(torch_cuda, name):
+    """The reference's own PhotonIntegrator + PhotonVolumeIntegrator records (oracle/ref_capture.cpp `render ... surface`):
+    draws in front of every volume Li() and the stream ends exactly; Ls, T * Ls + Lvi and the film within 1e-4."""
+    from conftest import GOLD, blob
+    pvol = _pvol()
+    s, p, cam, film, smp, c = load_render_case(name)
+    cb = blob.load(os.path.join(GOLD, "caustic_vh.bin"))
+    pv = pvol.PhotonVolume(p)
+    try:
+        pv.set_scene(abi.SceneHolder(s))
+        pv.upload_photons(*load_photons(RENDER_SURF_CASES[name][1]))
+        pv.set_surface_integrator(int(c["surf.params.i"][0]), float(c["surf.params.f"][0]), 5, bool(c["surf.params.i"][1]),
+                                  (cb["p"].reshape(-1, 3), cb["wo"].reshape(-1, 3), cb["alpha"].reshape(-1, 30)), int(cb["n_paths"][0]))
+        n = len(c["samples.time"])
+        r = _render_surface(torch_cuda, pv, cam, film, smp, c["tasks"], n)
+        assert pv.march_kernel_name() == "li_group_kernel"
+        np.testing.assert_array_equal(r["xy"].ravel(), c["samples.image"])
+        np.testing.assert_array_equal(r["rays"]["maxt"], c["rays.t"][1::2])
+        np.testing.assert_array_equal(r["rays"]["rng_skip"], c["rays.skip"])          # sampler draws + the surface integrator's
+        np.testing.assert_array_equal(r["streams"]["end_draw"], c["task.end_draw"])
+        ref_s = c["surf.xyz"].reshape(-1, 3)
+        assert (ref_s.sum(1) > 0).mean() > 0.5
+        err = _rel_l2(r["surf_xyz"], ref_s)
+        assert err.max() <= 1e-4, "surface Li per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        ref = c["xyzT"].reshape(-1, 4)
+        err = _rel_l2(r["xyzT"][:, :3], ref[:, :3])
+        assert err.max() <= 1e-4, "T * Ls + Lvi per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        refpix = c["film.pixels"].reshape(film.y_resolution, film.x_resolution, 4)
+        np.testing.assert_allclose(r["pixels"], refpix, rtol=1e-4, atol=1e-5 * np.abs(refpix).max())
+        # switched off again: the volume-only records of the same frame come back
+        pv.set_surface_integrator(off=True)
+        r0 = _render_surface(torch_cuda, pv, cam, film, smp, c["tasks"], n)
+        assert (r0["rays"]["rng_skip"] <= c["rays.skip"]).all() and (r0["surf_xyz"] == 0).all()
+        assert np.abs(r0["xyzT"][:, :3]).sum() < np.abs(r["xyzT"][:, :3]).sum()
+    finally:
+        pv.close()
+
+
+def test_surface_integrator_refuses_what_it_does_not_cover(torch_cuda):
+    pvol = _pvol()
+    # glass triangles: the recursion of SpecularReflect / SpecularTransmit is not implemented
+    s = load_scene("pinkfloyd")
+    pv = pvol.PhotonVolume(abi.params_from_blob(s))
+    try:
+        pv.set_scene(abi.SceneHolder(s))
+        with pytest.raises(pvol.PvolError) as e:
+            pv.set_surface_integrator(50, 0.1)
+        assert e.value.status == abi.PVOL_E_UNSUPPORTED
+    finally:
+        pv.close()
+    # a heterogeneous medium: the surface term needs li_group_kernel's optical length, which the grid path does not report
+    s, p, cam, film, smp, c = load_render_case("grid16")
+    pv = pvol.PhotonVolume(p)
+    try:
+        pv.set_scene(abi.SceneHolder(s))
+        pv.upload_photons(*load_photons(RENDER_CASES["grid16"][1]))
+        pv.set_surface_integrator(50, 0.1)
+        with pytest.raises(pvol.PvolError) as e:
+            _render_surface(torch_cuda, pv, cam, film, smp, c["tasks"], len(c["samples.time"]))
+        assert e.value.status == abi.PVOL_E_UNSUPPORTED
+    finally:
+        pv.close()
+
+
+@pytest.mark.parametrize("n_used,max_dist", [(4, 0.6), (12, 1.0)])
+def test_surface_integrator_nearest_k_branch_matches_oracle(torch_cuda, orc, n_used, max_dist):
+    """The capture's caustic map is sparse (at most 10 photons within maxdist of a hit, nused 300): every lookup there takes the
+    'fewer than nused' branch.  A small nused over a wide maxdist makes the heap of PhotonProcess fill and shrink the radius
+    (kdtree.h:176-206): the k nearest, the shrunk maxDistSquared in the kernel weight and in the density estimate."""
+    from conftest import GOLD, blob
+    pvol = _pvol()
+    s, p, cam, film, smp, c = load_render_case("vh_surf64")
+    cb = blob.load(os.path.join(GOLD, "caustic_vh.bin"))
+    caustic = (cb["p"].reshape(-1, 3), cb["wo"].reshape(-1, 3), cb["alpha"].reshape(-1, 30))
+    holder = abi.SceneHolder(s)
+    o = orc.Oracle(holder, p)
+    o.set_photons(*load_photons("vh"))
+    o.set_surface_integrator(n_used, max_dist, False, caustic, int(cb["n_paths"][0]))
+    ref = orc.render_tasks(o, cam, film, smp, c["tasks"])
+    assert not ref["unsupported_hits"]
+    pv = pvol.PhotonVolume(p)
+    try:
+        pv.set_scene(holder)
+        pv.upload_photons(*load_photons("vh"))
+        pv.set_surface_integrator(n_used, max_dist, 5, False, caustic, int(cb["n_paths"][0]))
+        n = len(c["samples.time"])
+        r = _render_surface(torch_cuda, pv, cam, film, smp, c["tasks"], n)
+        np.testing.assert_array_equal(r["rays"]["rng_skip"], ref["rays"]["rng_skip"])
+        np.testing.assert_array_equal(r["streams"]["end_draw"], ref["end_draws"])
+        err = _rel_l2(r["surf_xyz"], ref["surf_xyz"].reshape(-1, 3))
+        assert err.max() <= 1e-4, "surface Li per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        err = _rel_l2(r["xyzT"][:, :3], ref["xyzT"].reshape(-1, 4)[:, :3])
+        assert err.max() <= 1e-4, "T * Ls + Lvi per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        np.testing.assert_allclose(r["pixels"], ref["pixels"].reshape(r["pixels"].shape), rtol=1e-4, atol=1e-5 * np.abs(ref["pixels"]).max())
+    finally:
+        pv.close()

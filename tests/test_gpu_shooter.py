@@ -110,7 +110,8 @@ def test_surface_stores_match_oracle(pvol, orc, scene_name, n_photons, n_tasks):
         # direct + indirect deposits too.  Kept small on purpose: with indirect photons wanted, paths continue after DIFFUSE bounces,
         # whose directions pass through sinf/cosf (device and glibc differ in the last ulp); among ~10^6 such bounces one roulette
         # or hit decision flips and that task's stream leaves the oracle's -- equal in distribution, not photon for photon
-        over.update({"n_indirect_photons": 40})
+        # caustic photons here come through the medium only, and stop once the volume map is full: few enough to arrive first
+        over.update({"n_indirect_photons": 40, "n_caustic_photons": 100})
     p = abi.params_from_blob(s, n_volume_photons=n_photons, **over)
     o = orc.Oracle(h, p)
     o.keep_surface_photons(True)
@@ -142,3 +143,24 @@ def test_surface_stores_match_oracle(pvol, orc, scene_name, n_photons, n_tasks):
     # the volume map is the same as without the stores
     assert len(pv.download_photons()[0]) == len(o.get_photons()[0])
     pv.close()
+
+
+def test_a_store_that_stops_growing_ends_the_pass(pvol, orc):
+    """volumescene has no specular surface: its 'caustic' photons all pass through the medium, and none arrives once the volume
+    map is full.  The reference's abort test (photonshooter.cpp:37-39) is satisfied by the early ones and it would shoot forever;
+    the product (and the oracle, so that tests end) give up after 256 rounds without a photon for any store still wanted."""
+    s = load_scene("volumescene_h")
+    h = abi.SceneHolder(s)
+    p = abi.params_from_blob(s, n_volume_photons=150, n_indirect_photons=0, n_caustic_photons=4000)
+    o = orc.Oracle(h, p)
+    assert o.shoot(2, 8) == abi.PVOL_E_SHOOT_FAILED
+    pv = pvol.PhotonVolume(p)
+    try:
+        pv.set_scene(h)
+        with pytest.raises(pvol.PvolError) as e:
+            pv.preprocess(2)
+        assert e.value.status == abi.PVOL_E_SHOOT_FAILED
+        assert pv.photon_count() == 0
+        assert pv.shoot_stats()["nshot"] == o.shoot_stats()["nshot"]
+    finally:
+        pv.close()

@@ -903,10 +903,19 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     const f4 X4 = ld4(S.cieX, q), Y4 = ld4(S.cieY, q), Z4 = ld4(S.cieZ, q);
     WaveCounters wc = {};
     unsigned long long tk0 = STATS ? stamp() : 0ull;
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+    // Runs of 64 consecutive entries per wave: the list is filled group by group, so neighbours in the list are neighbours in
+    // space (the 64 rays of a group at one march step) and the k-th distance^2 just found is the first radius of the next lookup.
+    // An entry without a guess of its own (nused beyond the bucket plan hands everything over unseen) would otherwise scan the
+    // whole maxdist ball -- tens of thousands of photons inside pinkfloyd's beams.  A wrong first radius costs a retry, never
+    // the result: lphoton() widens it until the k nearest are inside.
+    float carry = 0.f;
+    for (uint32_t e0 = blockIdx.x * 64u; e0 < n; e0 += gridDim.x * 64u)
+    for (uint32_t e = e0; e < min(e0 + 64u, n); ++e) {
         const DeferRec r = A.defer[e];
         float rk;
-        const f4 Lii = lphoton<STATS, NREG>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4 * r.dens, lane, wc, r.guess, &rk);   // g == 0: the direction is not read
+        const float first = r.guess > 0.f ? r.guess : (carry > 0.f ? carry : S.rkEstimate);
+        const f4 Lii = lphoton<STATS, NREG>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4 * r.dens, lane, wc, first, &rk);   // g == 0: the direction is not read
+        carry = rk > 0.f ? rk : S.maxDistSq;   // fewer than nused within maxdist: sparse here, the full ball is the cheap radius
         const f4 kk = sigT4 * r.kRem;
         f4 c = make_float4(__builtin_amdgcn_exp2f(kk.x), __builtin_amdgcn_exp2f(kk.y), __builtin_amdgcn_exp2f(kk.z), __builtin_amdgcn_exp2f(kk.w));
         c = clean4(c * (sigS4 * (albedo4 * Lii) * r.stepD), q);

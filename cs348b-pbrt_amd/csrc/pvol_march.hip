@@ -1309,19 +1309,35 @@ __global__ __launch_bounds__(LANES) void li_resolve_lite_kernel(LiArgs A) {
             } else {
                 rng_skip<true>(rng, 4ull + 6ull * (unsigned long long)n, lane);
             }
-            for (int i = 0; i < n; ++i) {
-                const float uTau = rng_float<true>(rng, lane);
-                const unsigned int mask = rec.stepByte[i];
-                unsigned int outByte = 0u;
-                float uSh = 0.f;
-                if (mask & 0x80u) {
-                    int ln = 0;
-                    if (nLights > 1) ln = min((int)floorf(lightNum[i] * nLights), nLights - 1);
-                    outByte = (unsigned int)ln;
-                    if ((mask >> ln) & 1u) uSh = rng_float<true>(rng, lane);
-                }
-                if (lane == 0) {
-                    rec.stepByte[i] = (unsigned char)outByte;
+            // one march step per lane: step i draws uTau, then uSh if its light sample is unoccluded -- the positions are the
+            // exclusive scan of (1 + shadowed) over the steps, the values come 64 at a time out of the LDS state
+            for (int base = 0; base < n; base += LANES) {
+                const int i = base + lane;
+                const bool on = i < n;
+                const unsigned int mask = on ? rec.stepByte[i] : 0u;
+                int ln = 0;
+                if (nLights > 1 && on) ln = min((int)floorf(lightNum[i] * nLights), nLights - 1);
+                const bool lit = on && (mask & 0x80u) != 0u;
+                const bool sh = lit && ((mask >> ln) & 1u) != 0u;
+                const uint32_t need = on ? (sh ? 2u : 1u) : 0u;
+                uint32_t incl = need;
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+                const uint32_t off = incl - need;
+                const int total = lane_i((int)incl, LANES - 1);   // <= 128
+                const uint32_t dA = rng_bulk(rng, min(total, LANES), lane);
+                const uint32_t dB = total > LANES ? rng_bulk(rng, total - LANES, lane) : 0u;
+                const uint32_t o1 = off + 1u;
+                const uint32_t t0 = (uint32_t)__shfl((int)dA, (int)(off & 63u)), t1 = (uint32_t)__shfl((int)dB, (int)(off & 63u));
+                const uint32_t s0 = (uint32_t)__shfl((int)dA, (int)(o1 & 63u)), s1 = (uint32_t)__shfl((int)dB, (int)(o1 & 63u));
+                const float uTau = ((off < 64u ? t0 : t1) & 0xffffff) / float(1 << 24);   // core/rng.cpp:59-65
+                const float uSh = sh ? ((o1 < 64u ? s0 : s1) & 0xffffff) / float(1 << 24) : 0.f;
+                if (on) {
+                    rec.stepByte[i] = (unsigned char)(lit ? (unsigned int)ln : 0u);
                     if (grid) { rec.stepU[2 * i] = uTau; rec.stepU[2 * i + 1] = uSh; }
                 }
             }

@@ -81,6 +81,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
     { const char *nl = getenv("PVOL_NO_LITE"); c->noLite = nl && nl[0] == '1'; }
     { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 12; }
+    { const char *fw = getenv("PVOL_FIX_WAVES"); c->fixWavesPerCU = fw ? std::max(1, atoi(fw)) : 8; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
@@ -613,7 +614,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     if (par) hipMemsetAsync(c->dWords, 0, 3 * sizeof(uint32_t), stream);
     if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel
         a.sliceK = 0; a.sliceM = 0xffffffc0u; a.state = 0;
-        if (!ok(pvol_launch_tile(&a, tile, false, pvol_tile_lds_bytes(0, tile->spp, false), c->hs.candCap, stream))) return PVOL_E_NO_DEVICE;
+        if (!ok(pvol_launch_tile(&a, tile, false, pvol_tile_lds_bytes(0, tile->spp, false, c->hs.nTris, c->hs.nLights > 0 && c->hs.lights[0].kind == PVOL_LIGHT_DISTANT), c->hs.candCap, stream))) return PVOL_E_NO_DEVICE;
     }
     hipEventRecord(ev.first, stream);
     if (par) {
@@ -637,7 +638,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
                 c->deferCap = wantDefer;
             }
             a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
-            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, (uint32_t)c->nCU * 8u, 0, stream);
+            e = pvol_launch_li_group(&a, pvol_group_lds_bytes(c->hs.candCap), c->hs.candCap, c->statsOn, gWaves, (uint32_t)(c->nCU * c->fixWavesPerCU), 0, stream);
             c->lastKernel = "li_group_kernel";
         } else {
             c->lastKernel = "li_par_kernel";
@@ -677,19 +678,20 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
                 c->deferCap = wantDefer;
             }
             a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
+            a.fixGroup = (c->hs.nUsed > 100 && !getenv("PVOL_FIX_EXACT")) ? 1 : 0;   // GRP_PLAN_KMAX: see pvol_fixgrp_dev.h
             c->lastKernel = "li_group_kernel";
         }
         if (tileGridCount) {   // sampler + camera + draw COUNT for the whole batch, once
             LiArgs t = a;
             t.sliceK = 0; t.sliceM = 0xffffffc0u; t.state = 0;
-            e = pvol_launch_tile(&t, tile, false, pvol_tile_lds_bytes(0, tile->spp, false), c->hs.candCap, stream);
+            e = pvol_launch_tile(&t, tile, false, pvol_tile_lds_bytes(0, tile->spp, false, c->hs.nTris, c->hs.nLights > 0 && c->hs.lights[0].kind == PVOL_LIGHT_DISTANT), c->hs.candCap, stream);
         }
         for (uint32_t k = 0; k < nSlices && ok(e); ++k) {
             a.sliceK = k;
             hipMemsetAsync(c->dWords, 0, 4 * sizeof(uint32_t), stream);
-            if (tile && !tileGridCount) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true), c->hs.candCap, stream);
+            if (tile && !tileGridCount) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true, c->hs.nTris, false), c->hs.candCap, stream);
             if (ok(e)) e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream,
-                                                tile == 0 || tileGridCount, groupForm, pvol_group_lds_bytes(c->hs.candCap), gWaves, (uint32_t)c->nCU * 8u);
+                                                tile == 0 || tileGridCount, groupForm, pvol_group_lds_bytes(c->hs.candCap), gWaves, (uint32_t)(c->nCU * c->fixWavesPerCU));
         }
     } else {
         c->lastKernel = "li_seq_kernel";

@@ -1,0 +1,362 @@
+// pvol_fixgrp_dev.h -- li_fixup_group_kernel: the exact k-nearest lookups li_group_kernel hands over when nused lies beyond its
+// bucket plan (C3: nused 500), one lookup per LANE, 64 neighbouring lookups sharing one staged bucket.
+//
+// Why: a k = 500 lookup reads 500 photon rows of 128 B.  One wave per lookup (li_fixup_kernel) moves 64 KB per lookup and
+// spends its time on dependent memory round trips; the 64 lookups of a group at one march step (neighbouring rays, same depth)
+// want nearly the same photons, so here the union of their search balls is staged ONCE in LDS, every lane selects its own
+// k nearest out of it, and the flux rows are read once per 64 lookups through the scalar cache.
+//
+// Selection per lane (kdtree.h:157-206 keeps the nused nearest and shrinks maxDistSquared to the farthest of them):
+//   A  histogram of DistanceSquared over the bucket: 64 bins on [0, T_lane), 8-bit counters packed four to an LDS word per
+//      lane (ds_add_u32); a byte that wrapped shows as sum != the exact in-range count and sends the lane to the exact pass
+//   B  the bin that holds the k-th: histogram again over 64 sub-bins of that bin
+//   C  the sub-bin that holds it: its members (<= 8, else the exact pass) are collected and ordered in registers: the k-th
+//      DistanceSquared itself, bit for bit, and how many photons AT that value still belong (ties, bucket order)
+//   D  flux: sum of alpha over the members, one 128-B row per photon through the scalar cache, a 0/1 factor per lane
+// Bins are floor(d2 * 64 / T) and floor(frac * 64): monotone in d2, so every pass narrows the same order statistics; what
+// decides membership in the end is the comparison with the k-th value found in C, never a bin.
+//
+// The first radius^2 of a run comes from a density probe (photon counts of the grid cells around the run's first point, read
+// from the cell-start prefix sums), not from a neighbour's result: runs arrive from all over the frame.  A lane whose ball held
+// fewer than nused photons grows it by what its count says (like lphoton()) and joins a later bucket; after three tries, or
+// when one point's own ball overflows the bucket, the wave-cooperative lphoton() serves it -- the slow path, exact as well.
+#ifndef PVOL_FIXGRP_DEV_H
+#define PVOL_FIXGRP_DEV_H
+
+#define FXG_CAP 1536   // bucket slots (positions + photon index: 16 B each)
+#define FXG_MINI 8
+
+// photons in the grid cells that overlap the cube c +- h, and the volume of those cells
+__device__ __forceinline__ uint32_t box_count(const GridView &g, V3 c, float h, int lane, float *vol) {
+    const float inv = g.invCell;
+    int x0 = (int)floorf((c.x - h - g.gridLo[0]) * inv), x1 = (int)floorf((c.x + h - g.gridLo[0]) * inv);
+    int y0 = (int)floorf((c.y - h - g.gridLo[1]) * inv), y1 = (int)floorf((c.y + h - g.gridLo[1]) * inv);
+    int z0 = (int)floorf((c.z - h - g.gridLo[2]) * inv), z1 = (int)floorf((c.z + h - g.gridLo[2]) * inv);
+    // volume of the cells counted; where the cube sticks out of the photons' bounds those cells are empty, and counted as such
+    *vol = (float)(x1 - x0 + 1) * (float)(y1 - y0 + 1) * (float)(z1 - z0 + 1) * (g.cellSize * g.cellSize * g.cellSize);
+    x0 = max(x0, 0); y0 = max(y0, 0); z0 = max(z0, 0);
+    x1 = min(x1, g.gdim[0] - 1); y1 = min(y1, g.gdim[1] - 1); z1 = min(z1, g.gdim[2] - 1);
+    if (x0 > x1 || y0 > y1 || z0 > z1) return 0u;
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1, rows = ny * nz;
+    uint32_t tot = 0u;
+    for (int rb = 0; rb < rows; rb += LANES) {
+        const int r = rb + lane;
+        if (r < rows) {
+            const int iz = r / ny, iy = r - iz * ny;
+            const size_t base = ((size_t)(z0 + iz) * g.gdim[1] + (y0 + iy)) * g.gdim[0];
+            tot += g.cellStart[base + x1 + 1] - g.cellStart[base + x0];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
+    return tot;
+}
+
+__device__ __forceinline__ void fxg_clear(uint32_t *hist, int lane) {
+#pragma unroll
+    for (int w = 0; w < 16; ++w) hist[w * LANES + lane] = 0u;
+}
+
+// first bin whose running count reaches `want` (>= 1); returns false if the 64 bins hold fewer
+__device__ __forceinline__ bool fxg_scan(const uint32_t *hist, int lane, uint32_t want, uint32_t *bin, uint32_t *below, uint32_t *inBin, uint32_t *total) {
+    uint32_t cum = 0u, b = 0u, bel = 0u, cnt = 0u;
+    bool found = false;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const uint32_t word = hist[w * LANES + lane];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const uint32_t c = (word >> (8 * s)) & 255u;
+            if (!found && cum + c >= want) { found = true; b = (uint32_t)(4 * w + s); bel = cum; cnt = c; }
+            cum += c;
+        }
+    }
+    *bin = b; *below = bel; *inBin = cnt; *total = cum;
+    return found;
+}
+
+template <bool SPECTRAL>
+__global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const DevScene &S = *A.scene;
+    const int lane = threadIdx.x;
+    if (*A.needSeq != 0u) return;   // the whole batch is redone sequentially
+    const uint32_t n = min(*A.deferCount, A.deferCap);
+    constexpr int PITCH = FXG_CAP + 4;
+    float *bucket = reinterpret_cast<float *>(lds);
+    const float *bX = bucket, *bY = bucket + PITCH, *bZ = bucket + 2 * PITCH, *bI = bucket + 3 * PITCH;
+    uint32_t *paint = reinterpret_cast<uint32_t *>(bucket + 4 * PITCH);
+    uint32_t *hist = paint + PAINT_CAP;   // [16 words][64 lanes]
+    Gather G;                             // the slow path's candidate lists alias the bucket (never live together)
+    G.cap = S.candCap; G.cd = bucket; G.ci = reinterpret_cast<uint32_t *>(bucket + S.candCap); G.paint = paint;
+    const GridView gv = volume_grid(S);
+    const int k = S.nUsed;
+    const float wIso = 1.f / (4.f * K_PI);
+    const int q = lane & 7;
+    const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
+    const f4 sigT4 = sigA4 + sigS4;
+    const f4 albedo4 = clean4(fdiv4(sigS4, sigT4), q);
+    const f4 X4 = ld4(S.cieX, q), Y4 = ld4(S.cieY, q), Z4 = ld4(S.cieZ, q);
+    WaveCounters wc = {};
+    typedef const __attribute__((address_space(4))) nf4 cf4;
+    float carry = 0.f;
+    for (uint32_t r0 = blockIdx.x * (uint32_t)LANES; r0 < n; r0 += gridDim.x * (uint32_t)LANES) {
+        const uint32_t e = r0 + (uint32_t)lane;
+        DeferRec r;
+        r.ray = 0xffffffffu; r.px = r.py = r.pz = 0.f; r.kRem = 0.f; r.stepD = 0.f; r.guess = 0.f; r.dens = 1.f;
+        if (e < n) r = A.defer[e];
+        const bool valid = r.ray != 0xffffffffu;
+        const V3 p = v3(r.px, r.py, r.pz);
+        float acc[32];
+#pragma unroll
+        for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+        float distSq = 0.f;       // what the density estimate divides by: the k-th distance^2, or the farthest of a short set
+        int nFound = 0;
+        bool served = false;      // acc / distSq / nFound hold this lane's lookup
+        float Twant = 0.f;
+        int tries = 0;
+        unsigned long long pending = __ballot(valid), slow = 0ull;
+        bool alone = false, probed = false;
+        int shrinks = 0;
+        float Trun = carry > 0.f ? carry : S.rkEstimate;
+        while (pending) {
+            const bool waiting = ((pending >> lane) & 1ull) != 0ull;
+            const int piv = __ffsll((long long)pending) - 1;
+            const V3 c = v3(lane_f(p.x, piv), lane_f(p.y, piv), lane_f(p.z, piv));
+            if (!probed) {
+                // ---- first radius of the run: the ball that should hold ~1.4 nused photons at the density around the pivot
+                float T = fminf(Trun, S.maxDistSq);
+                for (int it = 0; it < 4; ++it) {
+                    float vol;
+                    const uint32_t cnt = box_count(gv, c, sqrtf(T), lane, &vol);
+                    const float pred = (float)cnt * (4.18879020478639f * T * sqrtf(T)) / vol;   // photons in the ball at the cube's density
+                    const float want = 1.4f * (float)k;
+                    if (pred >= 1.15f * (float)k && pred <= 2.0f * (float)k) break;
+                    if (pred < (float)k && T >= S.maxDistSq) break;
+                    const float ratio = want / fmaxf(pred, 0.05f * want);   // at most 20x the volume per probe
+                    T = fminf(S.maxDistSq, T * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf(ratio)));
+                }
+                Trun = T;
+                probed = true;
+                if (valid && tries == 0) Twant = Trun;
+            }
+            // ---- cluster: the waiting lookups within a quarter radius of the pivot (all 64 of a group-step, usually)
+            const float Tp = lane_f(Twant, piv);
+            const float dPiv = len(p - c);
+            const bool in = waiting && (alone ? lane == piv : dPiv <= 0.25f * sqrtf(Tp));
+            const float Tmax = wave_max(in ? Twant : 0.f);
+            const float spread = wave_max(in ? dPiv : 0.f);
+            const float Rs = (sqrtf(Tmax) + spread) * 1.0001f + 1e-6f;
+            unsigned long long tst = 0;
+            __syncthreads();
+            const int Mb = stage_bucket_g<FXG_CAP>(gv, G, bucket, c, Rs, lane, tst);
+            if (Mb < 0) {
+                if (!alone) { alone = true; continue; }   // first the pivot on its own
+                alone = false;
+                // the pivot's own ball overflows the bucket.  A radius that only the probe chose can shrink (half the volume for
+                // everyone still at it; a ball that turns out too small grows again below); one that grew because the lane
+                // counted too few is what the lookup needs: the exact pass takes it.
+                if (lane_i(tries, piv) == 0 && shrinks < 8) {
+                    ++shrinks;
+                    if (waiting && tries == 0) Twant = fminf(Twant, Tp * 0.62996f);
+                    continue;
+                }
+                slow |= 1ull << piv; pending &= ~(1ull << piv);
+                continue;
+            }
+            alone = false;
+            // ---- A: in-range count and 64-bin histogram of this lane's DistanceSquared values
+            const float Tl = Twant;
+            const float scale = in ? 64.f / Tl : 0.f;
+            const nf4 px4 = {p.x, p.x, p.x, p.x}, py4 = {p.y, p.y, p.y, p.y}, pz4 = {p.z, p.z, p.z, p.z};
+            fxg_clear(hist, lane);
+            __syncthreads();
+            int nIn = 0;
+            float maxIn = 0.f;
+            for (int i = 0; i < Mb; i += 4) {
+                const nf4 dx = *reinterpret_cast<const nf4 *>(bX + i) - px4, dy = *reinterpret_cast<const nf4 *>(bY + i) - py4,
+                          dz = *reinterpret_cast<const nf4 *>(bZ + i) - pz4;
+                const nf4 dd = dx * dx + dy * dy + dz * dz;   // DistanceSquared(photon.p, p), kdtree.h:180
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool inside = in && dd[u] < Tl;
+                    nIn += inside ? 1 : 0;
+                    maxIn = inside ? fmaxf(maxIn, dd[u]) : maxIn;
+                    const uint32_t bin = (uint32_t)fminf(dd[u] * scale, 63.f);   // fminf also absorbs the sentinels' inf
+                    atomicAdd(&hist[(bin >> 2) * LANES + lane], inside ? 1u << ((bin & 3u) << 3) : 0u);
+                }
+            }
+            __syncthreads();
+            bool ok = false, toSlow = false;
+            float kth = INFINITY;     // members: d2 < kth, plus tieQuota photons at d2 == kth
+            int tieQuota = 0;
+            uint32_t bstar = 0u, below = 0u, inBin = 0u, total = 0u;
+            const bool full = in && nIn >= k;
+            if (in && !full) {
+                if (Tl >= S.maxDistSq) { ok = true; }   // fewer than nused within maxdist: all of them (photonvolume.cpp:83 decides on the count)
+            }
+            if (__ballot(full)) {
+                const bool f1 = fxg_scan(hist, lane, (uint32_t)k, &bstar, &below, &inBin, &total);
+                if (full && (!f1 || total != (uint32_t)nIn)) toSlow = true;   // a byte wrapped
+                // ---- B: 64 sub-bins of the bin that holds the k-th
+                const bool selB = full && !toSlow;
+                const float fb = (float)bstar;
+                fxg_clear(hist, lane);
+                __syncthreads();
+                for (int i = 0; i < Mb; i += 4) {
+                    const nf4 dx = *reinterpret_cast<const nf4 *>(bX + i) - px4, dy = *reinterpret_cast<const nf4 *>(bY + i) - py4,
+                              dz = *reinterpret_cast<const nf4 *>(bZ + i) - pz4;
+                    const nf4 dd = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float f = dd[u] * scale;
+                        const bool hitB = selB && dd[u] < Tl && (uint32_t)fminf(f, 63.f) == bstar;
+                        const uint32_t sub = (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f);
+                        atomicAdd(&hist[(sub >> 2) * LANES + lane], hitB ? 1u << ((sub & 3u) << 3) : 0u);
+                    }
+                }
+                __syncthreads();
+                uint32_t sstar = 0u, below2 = 0u, inSub = 0u, total2 = 0u;
+                const uint32_t need1 = (uint32_t)k - below;   // rank of the k-th inside its bin, >= 1
+                const bool f2 = fxg_scan(hist, lane, need1, &sstar, &below2, &inSub, &total2);
+                if (selB && (!f2 || total2 != inBin || inSub > (uint32_t)FXG_MINI)) toSlow = true;
+                // ---- C: the members of that sub-bin, ordered
+                const bool selC = selB && !toSlow;
+                float mini[FXG_MINI];
+#pragma unroll
+                for (int m = 0; m < FXG_MINI; ++m) mini[m] = INFINITY;
+                for (int i = 0; i < Mb; i += 4) {
+                    const nf4 dx = *reinterpret_cast<const nf4 *>(bX + i) - px4, dy = *reinterpret_cast<const nf4 *>(bY + i) - py4,
+                              dz = *reinterpret_cast<const nf4 *>(bZ + i) - pz4;
+                    const nf4 dd = dx * dx + dy * dy + dz * dz;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float f = dd[u] * scale;
+                        const bool hitC = selC && dd[u] < Tl && (uint32_t)fminf(f, 63.f) == bstar && (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f) == sstar;
+                        if (__ballot(hitC)) {
+                            float v = hitC ? dd[u] : INFINITY;   // insertion into the ascending list
+#pragma unroll
+                            for (int m = 0; m < FXG_MINI; ++m) { const float lo = fminf(mini[m], v); v = fmaxf(mini[m], v); mini[m] = lo; }
+                        }
+                    }
+                }
+                if (selC) {
+                    const uint32_t need2 = need1 - below2;   // 1 .. inSub
+                    float kv = mini[0];
+#pragma unroll
+                    for (int m = 1; m < FXG_MINI; ++m) kv = (need2 == (uint32_t)(m + 1)) ? mini[m] : kv;
+                    int lessInList = 0;
+#pragma unroll
+                    for (int m = 0; m < FXG_MINI; ++m) lessInList += mini[m] < kv ? 1 : 0;
+                    kth = kv;
+                    tieQuota = k - (int)(below + below2) - lessInList;
+                    ok = true;
+                }
+            }
+            // ---- D: flux of the members
+            const bool doFlux = ok && (full || nIn >= 10);
+            if (__ballot(doFlux)) {
+                int tq = tieQuota;
+                for (int i = 0; i < Mb; ++i) {
+                    const float dx = bX[i] - p.x, dy = bY[i] - p.y, dz = bZ[i] - p.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    bool mem = doFlux && d2 < Tl && d2 < kth;
+                    if (doFlux && d2 == kth && tq > 0) { mem = true; --tq; }
+                    if (!__ballot(mem)) continue;
+                    const uint32_t pidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[i]));
+                    const float wgt = mem ? wIso : 0.f;
+                    cf4 *row = (cf4 *)(S.alpha4 + (size_t)pidx * 8);
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const nf4 rr = row[qq];
+                        acc[4 * qq] = __builtin_fmaf(rr.x, wgt, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rr.y, wgt, acc[4 * qq + 1]);
+                        acc[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, acc[4 * qq + 3]);
+                    }
+                }
+            }
+            if (ok) {
+                served = true;
+                nFound = full ? k : nIn;
+                distSq = full ? kth : maxIn;
+            }
+            // ---- lanes of the cluster that are not done: a larger ball next time, or the exact pass
+            const bool failed = in && !ok && !toSlow;   // fewer than nused inside a ball smaller than maxdist
+            if (failed) {
+                ++tries;
+                const float grow = nIn > 0 ? 1.35f * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf((float)k / (float)nIn)) : 8.f;
+                Twant = fminf(S.maxDistSq, Twant * fmaxf(1.5f, grow));
+                if (tries >= 3) toSlow = true;
+            }
+            slow |= __ballot(toSlow);
+            pending &= ~__ballot(ok || toSlow);
+        }
+        { const unsigned long long sv = __ballot(served); if (lane == 0 && sv) atomicAdd(&A.counters->diag[1], (unsigned long long)__popcll(sv)); }   // lookups served from shared buckets
+        // ---- what the next run starts its probe from
+        {
+            const float m = wave_max(served && nFound >= k ? distSq : 0.f);
+            carry = m > 0.f ? m : S.maxDistSq;
+        }
+        // ---- terms of the lanes served above:  exp(-sigma_t R_j) sigma_s step albedo L_ii,  L_ii = sum(alpha) phase / (4/3 pi r^3 sigma_s(p))
+        if (served && nFound >= 10) {
+            const float dV = distSq * sqrtf(distSq);
+            float liiScale = 0.f;
+            if (dV != 0.f && r.dens != 0.f) liiScale = __builtin_amdgcn_rcpf(float(4.0 / 3.0 * (double)K_PI * (double)dV)) * __builtin_amdgcn_rcpf(r.dens);
+            float x = 0.f, y = 0.f, z = 0.f;
+            float *ops = SPECTRAL ? A.out + (size_t)r.ray * 60 : 0;
+#pragma unroll
+            for (int b = 0; b < 30; ++b) {
+                const float sA = S.sigA[b], sS = S.sigS[b];
+                const float sT = sA + sS;
+                const float alb = __fdividef(sS, sT);
+                const float Lii = sS != 0.f ? acc[b] * liiScale * __builtin_amdgcn_rcpf(sS) : 0.f;
+                const float t = __builtin_amdgcn_exp2f(sT * r.kRem) * (sS * (alb * Lii) * r.stepD);
+                const float tc = (t == t) ? t : 0.f;
+                if (SPECTRAL) { if (tc != 0.f) atomicAdd(ops + b, tc); }
+                else { x += S.cieX[b] * tc; y += S.cieY[b] * tc; z += S.cieZ[b] * tc; }
+            }
+            if (!SPECTRAL) {
+                const float scale = float(700 - 400) / float(106.856895f * 30);
+                float *op = A.out + (size_t)r.ray * 4;
+                atomicAdd(op, x * scale); atomicAdd(op + 1, y * scale); atomicAdd(op + 2, z * scale);
+            }
+        }
+        // ---- the exact pass for what is left (one wave-cooperative lookup each)
+        while (slow) {
+            const int j = __ffsll((long long)slow) - 1;
+            slow &= slow - 1ull;
+            const V3 pj = v3(lane_f(p.x, j), lane_f(p.y, j), lane_f(p.z, j));
+            const float dens = lane_f(r.dens, j), kRem = lane_f(r.kRem, j), stepD = lane_f(r.stepD, j);
+            const uint32_t ray = (uint32_t)lane_i((int)r.ray, j);
+            float rk;
+            __syncthreads();
+            const f4 Lii = lphoton<false, 12>(S, G, v3(0.f, 0.f, 1.f), pj, sigS4 * dens, lane, wc, carry < S.maxDistSq ? carry : 0.f, &rk);
+            if (rk > 0.f) carry = rk;
+            const f4 kk = sigT4 * kRem;
+            f4 c = make_float4(__builtin_amdgcn_exp2f(kk.x), __builtin_amdgcn_exp2f(kk.y), __builtin_amdgcn_exp2f(kk.z), __builtin_amdgcn_exp2f(kk.w));
+            c = clean4(c * (sigS4 * (albedo4 * Lii) * stepD), q);
+            if (SPECTRAL) {
+                if (lane < 8) {
+                    float *op = A.out + (size_t)ray * 60 + 4 * q;
+                    const float cv[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) if (4 * q + cc < 30 && cv[cc] != 0.f) atomicAdd(op + cc, cv[cc]);
+                }
+            } else {
+                const float scale = float(700 - 400) / float(106.856895f * 30);
+                const float x = group8_sum(X4.x * c.x + X4.y * c.y + X4.z * c.z + X4.w * c.w) * scale;
+                const float y = group8_sum(Y4.x * c.x + Y4.y * c.y + Y4.z * c.z + Y4.w * c.w) * scale;
+                const float z = group8_sum(Z4.x * c.x + Z4.y * c.y + Z4.z * c.z + Z4.w * c.w) * scale;
+                if (lane == 0) {
+                    float *op = A.out + (size_t)ray * 4;
+                    atomicAdd(op, x); atomicAdd(op + 1, y); atomicAdd(op + 2, z);
+                }
+            }
+            if (lane == 0) atomicAdd(&A.counters->diag[0], 1ull);   // exact-pass lookups (reported with the stats)
+        }
+    }
+}
+
+extern "C" size_t pvol_fixgrp_lds_bytes(int candCap) {
+    const size_t bucket = (size_t)(FXG_CAP + 4) * 16;
+    return std::max(bucket, (size_t)candCap * 8) + PAINT_CAP * 4 + 16 * LANES * 4;
+}
+#endif

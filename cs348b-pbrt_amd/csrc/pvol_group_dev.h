@@ -755,15 +755,18 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     // ---- lanes the plan did not serve: their term is added by li_fixup_kernel (exact lookup), nothing else waits for it
                     const uint64_t todo = __ballot(need && !done);
                     if (todo) {
-                        const int nfb = __popcll(todo);
+                        // A.fixGroup: whole 64-slot runs, one per group-step (li_fixup_group_kernel shares a bucket per run);
+                        // slots of lanes with nothing to hand over are marked empty
+                        const bool padded = A.fixGroup != 0;
+                        const int nfb = padded ? LANES : __popcll(todo);
                         uint32_t base = 0;
                         if (lane == 0) base = atomicAdd(A.deferCount, (uint32_t)nfb);
                         base = (uint32_t)lane_i((int)base, 0);
-                        if (need && !done) {
-                            const uint32_t at = base + lanes_below(todo, lane);
+                        if (padded || (need && !done)) {
+                            const uint32_t at = base + (padded ? (uint32_t)lane : lanes_below(todo, lane));
                             if (at < A.deferCap) {
                                 DeferRec r;
-                                r.ray = (uint32_t)ri; r.px = p.x; r.py = p.y; r.pz = p.z; r.kRem = kRem; r.stepD = stepD;
+                                r.ray = (need && !done) ? (uint32_t)ri : 0xffffffffu; r.px = p.x; r.py = p.y; r.pz = p.z; r.kRem = kRem; r.stepD = stepD;
                                 // the radius^2 the next attempt would have asked for is the best guess there is (lphoton widens it by 1.3)
                                 r.guess = fixedR ? 0.f : (Twant > 0.f ? Twant * (1.f / PVOL_GUESS_SCALE) : (guessBase > 0.f ? guessBase : 0.f)); r.dens = dens;
                                 A.defer[at] = r;
@@ -912,6 +915,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     for (uint32_t e0 = blockIdx.x * 64u; e0 < n; e0 += gridDim.x * 64u)
     for (uint32_t e = e0; e < min(e0 + 64u, n); ++e) {
         const DeferRec r = A.defer[e];
+        if (r.ray == 0xffffffffu) continue;   // padding of a 64-slot run
         float rk;
         const float first = r.guess > 0.f ? r.guess : (carry > 0.f ? carry : S.rkEstimate);
         const f4 Lii = lphoton<STATS, NREG>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4 * r.dens, lane, wc, first, &rk);   // g == 0: the direction is not read
@@ -942,6 +946,8 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
 
+#include "pvol_fixgrp_dev.h"   // li_fixup_group_kernel: the hand-over list of nused beyond the bucket plan, 64 lookups per staged bucket
+
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;
     return (size_t)PREV_N * 4 + GRP_CH * 2 + (size_t)GRP_PITCH * 16 + GRP_U_BYTES + 9 * 32 * 4 + GRP_TRI_ROWS * 64 + PVOL_MAX_LIGHTS * 32 * 4;
@@ -955,8 +961,11 @@ extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, 
     const bool spectral = args->outputKind == PVOL_OUT_SPECTRAL;
     const size_t fixLds = (size_t)candCap * 8 + PAINT_CAP * 4;
     const bool big = candCap > 4 * LANES;   // select_k registers of the exact lookup: 4 cover nused <= 64, 12 cover nused <= 576
+    const bool fixGroup = args->fixGroup != 0 && big && !stats;
+    const size_t fixGrpLds = pvol_fixgrp_lds_bytes(candCap);
 #define GRP_LAUNCH(ST, SP, RP, GR) hipLaunchKernelGGL((li_group_kernel<ST, SP, RP, GR>), grid, block, ldsBytes, stream, *args)
-#define FIX_LAUNCH(ST, SP) do { if (big) hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 12>), fgrid, block, fixLds, stream, *args); \
+#define FIX_LAUNCH(ST, SP) do { if (fixGroup) hipLaunchKernelGGL((li_fixup_group_kernel<SP>), fgrid, block, fixGrpLds, stream, *args); \
+                                else if (big) hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 12>), fgrid, block, fixLds, stream, *args); \
                                 else hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 4>), fgrid, block, fixLds, stream, *args); } while (0)
     if (replay == 0) {
         if (stats) { if (spectral) { GRP_LAUNCH(true, true, false, false); FIX_LAUNCH(true, true); } else { GRP_LAUNCH(true, false, false, false); FIX_LAUNCH(true, false); } }

@@ -32,6 +32,7 @@ struct LiArgs {
     uint32_t *deferCount;
     uint32_t deferCap;
     float *tauOut;              // optional: per ray the optical length of Li()'s last march step (T = exp(-sigma_t * tau))
+    int32_t fixGroup;           // nused beyond the bucket plan: the hand-over list is padded to 64-slot runs for li_fixup_group_kernel
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
@@ -51,7 +52,7 @@ extern "C" size_t pvol_group_lds_bytes(int candCap);
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
                                            int replay, hipStream_t stream);
 extern "C" hipError_t pvol_launch_surface(const SurfArgs *a, uint32_t nWaves, hipStream_t stream);
-extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused);
+extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused, int nTris, bool shadowRows);
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
@@ -76,6 +77,7 @@ struct pvol_ctx {
     float maxDensity = 1.f;   // largest density factor of the medium (1 for analytic volumes, max of the grid values)
     bool noLite = false;      // PVOL_NO_LITE=1: keep the geometry inside the sequential resolve pass (testing)
     const char *lastKernel = "";
+    int fixWavesPerCU;   // li_fixup_kernel waves per CU; PVOL_FIX_WAVES overrides
     int groupWavesPerCU; // resident li_group_kernel waves per CU (LDS plan: 8); PVOL_GROUP_WAVES overrides
     bool noGroup;       // PVOL_NO_GROUP=1: keep li_par_kernel (one wave per ray) where li_group_kernel (one ray per lane) would run
     bool forceSeq;      // PVOL_FORCE_SEQ=1: always take the stream-sequential kernel (testing)

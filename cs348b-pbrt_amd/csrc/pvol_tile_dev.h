@@ -220,7 +220,7 @@ __device__ uint32_t tile_count_draws(const DevScene &S, const CountConsts &C, co
 }
 
 template <bool FUSED, int NREG>
-__global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
+__global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, TileArgs T) {
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
     __syncthreads();
     float *trows = 0;
     if (!FUSED && S.nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT) {
-        trows = ltri + PVOL_MAX_TRIS * 12;
+        trows = ltri + S.nTris * 12;
         tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), trows, lane);
     }
     const pvol_stream st = A.streams[sidx];
@@ -343,8 +343,11 @@ __global__ __launch_bounds__(LANES) void tile_kernel(LiArgs A, TileArgs T) {
     }
 }
 
-extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused) {
-    return (((size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4 + 15) & ~(size_t)15) + PVOL_MAX_TRIS * 12 * 4 + PVOL_MAX_TRIS * 16 * 4 + 64;
+// LDS: MT19937 state | lightNum (fused) | the pixel's samples (5 words each) | triangles (12 words each) | their shadow rows
+// for a distant light (16 words each).  Sized by the scene: the resident waves per CU are LDS-bound (one task per wave).
+extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused, int nTris, bool shadowRows) {
+    return (((size_t)MT_N * 4 + (fused ? (size_t)((maxSteps + 1) & ~1) * 4 : 0) + (size_t)spp * 5 * 4 + 15) & ~(size_t)15) + (size_t)nTris * 12 * 4 +
+           (shadowRows ? (size_t)nTris * 16 * 4 : 0) + 64;
 }
 
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream) {

@@ -230,15 +230,20 @@ def _grid_scene(n):
     return s
 
 
-@pytest.mark.parametrize("case", ["grid128", "pinkfloyd_k500", "pinkfloyd_k50"])
+@pytest.mark.parametrize("case", ["grid128", "pinkfloyd_k500", "pinkfloyd_k500_exactpass", "pinkfloyd_k50"])
 def test_group_replay_form_matches_oracle(pvol, orc, case):
     """Scenes where drawn values reach the result run as RNG pre-pass + li_group_kernel's REPLAY form (+ the exact-lookup pass):
     C4's 128^3 VolumeGrid (trilinear density and stepped tau() per lane, recorded offsets), and pinkfloyd's two lights with
-    C3's nused 500 (fixed-radius plan, dense lookups handed to li_fixup_kernel) and with nused 50 (the bucket plan proper)."""
+    C3's nused 500 (fixed-radius plan, dense lookups handed to li_fixup_group_kernel: 64 lookups per staged bucket, histogram
+    selection of the 500 nearest; `_exactpass`: to li_fixup_kernel, one wave per lookup) and with nused 50 (the bucket plan proper)."""
+    import os
+    old_env = os.environ.pop("PVOL_FIX_EXACT", None)
+    if case == "pinkfloyd_k500_exactpass":
+        os.environ["PVOL_FIX_EXACT"] = "1"
     if case == "grid128":
         s = _grid_scene(128)
         over, n_photons, n_tasks, res, spp, tasks = {}, 200000, 2048, (256, 256), 16, [40, 130, 200]
-    elif case == "pinkfloyd_k500":
+    elif case.startswith("pinkfloyd_k500"):
         s = load_scene("pinkfloyd")
         over, n_photons, n_tasks, res, spp, tasks = {"n_caustic_photons": 0}, 400000, 64, (480, 270), 4, [100, 230, 300, 410]
     else:
@@ -267,5 +272,11 @@ def test_group_replay_form_matches_oracle(pvol, orc, case):
         pv.li(rays, g_end)
         o.li_batch(rays, o_end)
         assert (g_end["end_draw"] == o_end["end_draw"]).all()
+        if case == "pinkfloyd_k500":   # the shared-bucket pass did the work, the exact pass the odd lookup
+            st = pv.stats()
+            assert st["group_plan_skipped"] > 20 * max(1, st["group_guess_failed"]), (st["group_plan_skipped"], st["group_guess_failed"])
     finally:
         pv.close()
+        os.environ.pop("PVOL_FIX_EXACT", None)
+        if old_env is not None:
+            os.environ["PVOL_FIX_EXACT"] = old_env

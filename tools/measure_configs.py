@@ -110,6 +110,7 @@ def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n
         rgb = torch.zeros((yres, xres, 3), dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
         pv.kernel_time_ms(reset=True)
+        pv.stats(reset=True)
         t = time.perf_counter()
         pv.render_tasks(cam, film, smp, ids, px.data_ptr())
         pv.film_resolve(film, px.data_ptr(), rgb.data_ptr())
@@ -117,15 +118,31 @@ def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n
         wall = time.perf_counter() - t
         pv.check_errors()
         kms, nl = pv.kernel_time_ms()
+        work = pv.stats()
         rec["frame"] = {"xres": xres, "yres": yres, "spp": spp, "stated_size": stated, "render_tasks": int(n_tiles), "samples": int(n),
                         "kernel": pv.march_kernel_name(), "frame_s": wall, "Msamples_per_s_whole_pipeline": n / wall / 1e6,
                         "march_kernels_s": kms * nl * 1e-3, "Msamples_per_s_march_kernels": n / (kms * nl) / 1e3,
-                        "mean_rgb": float(rgb.mean().item())}
+                        "mean_rgb": float(rgb.mean().item()),
+                        # nused beyond the bucket plan (li_fixup_group_kernel): lookups served from shared buckets / by the exact pass
+                        "handed_over_shared_bucket": work["group_plan_skipped"], "handed_over_exact_pass": work["group_guess_failed"]}
     pv.close()
     print(json.dumps(rec), flush=True)
 
 
+def heartbeat(period=45.0):
+    """A line on stderr every `period` seconds: full-size frames run for minutes without output of their own."""
+    import threading
+    t0 = time.time()
+
+    def beat():
+        while True:
+            time.sleep(period)
+            print("[measure_configs] %.0f s" % (time.time() - t0), file=sys.stderr, flush=True)
+    threading.Thread(target=beat, daemon=True).start()
+
+
 if __name__ == "__main__":
+    heartbeat()
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     full = "--full" in sys.argv
     if "--no-li" in sys.argv:   # frames only (kernel traces)

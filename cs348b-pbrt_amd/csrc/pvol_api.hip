@@ -81,7 +81,8 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
     { const char *nl = getenv("PVOL_NO_LITE"); c->noLite = nl && nl[0] == '1'; }
     { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 12; }
-    { const char *fw = getenv("PVOL_FIX_WAVES"); c->fixWavesPerCU = fw ? std::max(1, atoi(fw)) : 8; }
+    // li_fixup_kernel / li_fixup_group_kernel waves per CU (C3, 8 spp frame: 16.3 s at 8, 13.9 s at 16)
+    { const char *fw = getenv("PVOL_FIX_WAVES"); c->fixWavesPerCU = fw ? std::max(1, atoi(fw)) : 16; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
     c->statsOn = false;
     c->timeMs = 0; c->launches = 0;
@@ -109,6 +110,8 @@ void pvol_free_photons(pvol_ctx *c) {
     if (c->dAlpha4) hipFree(c->dAlpha4);
     if (c->dWi4) hipFree(c->dWi4);
     if (c->dCellStart) hipFree(c->dCellStart);
+    if (c->dSubStart) hipFree(c->dSubStart);
+    c->dSubStart = 0;
     c->dRawP = c->dRawWi = c->dRawAlpha = 0;
     c->dPos4 = c->dAlpha4 = c->dWi4 = 0;
     c->dCellStart = 0;
@@ -361,10 +364,31 @@ int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions) {
     g.p = c->dRawP; g.wi = c->dRawWi; g.alpha = c->dRawAlpha; g.n = n;
     for (int a = 0; a < 3; ++a) { g.lo[a] = h.gridLo[a]; g.gdim[a] = h.gdim[a]; g.extLo[a] = h.extLo[a]; g.extHi[a] = h.extHi[a]; }
     g.inv = h.invCell;
+    g.sub = 1;
     g.volKind = h.volKind;
     memcpy(g.w2v, h.w2v, sizeof(g.w2v));
-    good = ok(pvol_build_grid(&g, c->dPos4, c->dAlpha4, c->dWi4, c->dCellStart, 0));
+    good = ok(pvol_build_grid(&g, c->dPos4, c->dAlpha4, c->dWi4, c->dCellStart, 0, 0));
     if (!good) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
+    // clumpy map (an average photon shares its cell with more than 64 others -- pinkfloyd's beams: 4 700): sort again with
+    // the 4 x 4 x 4 second level.  PVOL_SUBGRID=0/1 forces it off/on.
+    h.subStart = 0;
+    {
+        double sq = 0.0;
+        const char *ev = getenv("PVOL_SUBGRID");
+        bool want = false;
+        if (ev) want = atoi(ev) != 0;
+        else if (ok(pvol_grid_occupancy(c->dCellStart, (uint32_t)ncells, &sq, 0))) want = sq / (double)n > 64.0;
+        if (want && ncells * 64 < 0xfffffff0ull) {
+            if (ok(hipMalloc(&c->dSubStart, sizeof(uint32_t) * (ncells * 64 + 1)))) {
+                g.sub = 4;
+                if (!ok(pvol_build_grid(&g, c->dPos4, c->dAlpha4, c->dWi4, c->dCellStart, c->dSubStart, 0))) { pvol_free_photons(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
+                h.subStart = c->dSubStart;
+            } else {
+                c->dSubStart = 0;   // no room for the table: the coarse level alone is complete
+                (void)hipGetLastError();
+            }
+        }
+    }
     c->nPhotons = n;
     h.nPhotons = n; h.cellStart = c->dCellStart; h.pos4 = c->dPos4; h.alpha4 = c->dAlpha4; h.wi4 = c->dWi4;
     return pvol_push_scene(c);
@@ -379,7 +403,7 @@ int pvol_upload_photons(pvol_ctx *c, const float *p, const float *wi, const floa
     hipDeviceSynchronize();
     pvol_free_photons(c);
     DevScene &h = c->hs;
-    h.nPhotons = 0; h.cellStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
+    h.nPhotons = 0; h.cellStart = 0; h.subStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
     if (n == 0) return pvol_push_scene(c);
     bool good = ok(hipMalloc(&c->dRawP, sizeof(float) * 3 * (size_t)n)) && ok(hipMalloc(&c->dRawWi, sizeof(float) * 3 * (size_t)n)) &&
                 ok(hipMalloc(&c->dRawAlpha, sizeof(float) * 30 * (size_t)n));
@@ -469,7 +493,8 @@ int pvol_set_surface_integrator(pvol_ctx *c, const pvol_surface_params *sp, cons
         for (int a = 0; a < 3; ++a) { g.lo[a] = sf.gridLo[a]; g.gdim[a] = sf.gdim[a]; }
         g.inv = sf.invCell;
         g.volKind = PVOL_VOLUME_GRID;   // no Inside() filter: surface photons count wherever they lie
-        good = ok(pvol_build_grid(&g, c->dCPos4, c->dCAlpha4, c->dCWi4, c->dCCellStart, 0));
+        g.sub = 1;
+        good = ok(pvol_build_grid(&g, c->dCPos4, c->dCAlpha4, c->dCWi4, c->dCCellStart, 0, 0));
         if (!good) { drop(); pvol_free_caustic_map(c); pvol_push_scene(c); return PVOL_E_NO_DEVICE; }
         sf.nPhotons = n; sf.cellStart = c->dCCellStart; sf.pos4 = c->dCPos4; sf.alpha4 = c->dCAlpha4; sf.wi4 = c->dCWi4;
     }

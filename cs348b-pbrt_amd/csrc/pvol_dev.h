@@ -74,6 +74,7 @@ struct DevScene {
     int32_t gdim[3];
     int32_t ringMax;          // ceil(maxDist / cellSize), <= PVOL_MAX_RING
     const uint32_t *cellStart;
+    const uint32_t *subStart; // 4x4x4 sub-cells per cell (clumpy maps only, else 0): start of every sub-cell, x fastest
     const float4 *pos4;
     const float4 *alpha4;     // n * 8 float4
     const float4 *wi4;

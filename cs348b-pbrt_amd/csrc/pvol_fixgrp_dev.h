@@ -16,15 +16,18 @@
 // Bins are floor(d2 * 64 / T) and floor(frac * 64): monotone in d2, so every pass narrows the same order statistics; what
 // decides membership in the end is the comparison with the k-th value found in C, never a bin.
 //
+// Runs whose lookups are scattered relative to their radius (fxg_compact) are left to li_fixup_kernel.
 // The first radius^2 of a run comes from a density probe (photon counts of the grid cells around the run's first point, read
 // from the cell-start prefix sums), not from a neighbour's result: runs arrive from all over the frame.  A lane whose ball held
-// fewer than nused photons grows it by what its count says (like lphoton()) and joins a later bucket; after three tries, or
-// when one point's own ball overflows the bucket, the wave-cooperative lphoton() serves it -- the slow path, exact as well.
+// fewer than nused photons grows it by what its count says (like lphoton()) and joins a later bucket; one whose own ball
+// overflows the bucket shrinks it (bisecting between the two when it has seen both).  After FXG_TRIES corrections the
+// wave-cooperative lphoton() serves the lookup -- the slow path, exact as well.
 #ifndef PVOL_FIXGRP_DEV_H
 #define PVOL_FIXGRP_DEV_H
 
-#define FXG_CAP 1536   // bucket slots (positions + photon index: 16 B each)
+#define FXG_CAP 4096   // bucket slots: photon indices only (4 B each), eight times nused 500
 #define FXG_MINI 8
+#define FXG_TRIES 16  // radius corrections per lookup before the exact pass takes it
 
 // photons in the grid cells that overlap the cube c +- h, and the volume of those cells
 __device__ __forceinline__ uint32_t box_count(const GridView &g, V3 c, float h, int lane, float *vol) {
@@ -49,6 +52,39 @@ __device__ __forceinline__ uint32_t box_count(const GridView &g, V3 c, float h, 
     }
     for (int off = 32; off > 0; off >>= 1) tot += (uint32_t)__shfl_xor((int)tot, off);
     return tot;
+}
+
+// Radius^2 of the ball around c expected to hold ~1.4 k photons, from the photon counts of the grid cells around it (cube of
+// half side sqrt(T), at most four refinements of up to 20x the volume each).  Only a first guess: the lookups correct it.
+__device__ float probe_radius(const GridView &g, V3 c, float T0, int k, float maxT, int lane) {
+    float T = fminf(T0, maxT);
+    for (int it = 0; it < 4; ++it) {
+        float vol;
+        const uint32_t cnt = box_count(g, c, sqrtf(T), lane, &vol);
+        const float pred = (float)cnt * (4.18879020478639f * T * sqrtf(T)) / vol;   // photons in the ball at the cube's density
+        const float want = 1.4f * (float)k;
+        if (pred >= 1.15f * (float)k && pred <= 2.0f * (float)k) break;
+        if (pred < (float)k && T >= maxT) break;
+        const float ratio = want / fmaxf(pred, 0.05f * want);
+        T = fminf(maxT, T * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf(ratio)));
+    }
+    return T;
+}
+
+// Which of the two hand-over kernels serves a 64-slot run -- decided from the run alone, so both kernels agree without talking:
+// COMPACT (the lookups lie within a quarter of the probed radius of the first one: one staged bucket serves them all, lane per
+// lookup, li_fixup_group_kernel) or SCATTERED (few samples per pixel in a dense beam: every lookup has its own ball, and a wave
+// per lookup with 64 lanes on one candidate set is the better shape, li_fixup_kernel).  *Tprobe: first radius^2 for either.
+__device__ __forceinline__ bool fxg_compact(const GridView &g, const DevScene &S, bool valid, V3 p, int lane, float *Tprobe) {
+    const unsigned long long m = __ballot(valid);
+    *Tprobe = 0.f;
+    if (!m) return false;
+    const int piv = __ffsll((long long)m) - 1;
+    const V3 c = v3(lane_f(p.x, piv), lane_f(p.y, piv), lane_f(p.z, piv));
+    const float T = probe_radius(g, c, S.rkEstimate, S.nUsed, S.maxDistSq, lane);
+    *Tprobe = T;
+    const float spread = wave_max(valid ? len(p - c) : 0.f);
+    return spread <= 0.25f * sqrtf(T);
 }
 
 __device__ __forceinline__ void fxg_clear(uint32_t *hist, int lane) {
@@ -81,10 +117,9 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
     const int lane = threadIdx.x;
     if (*A.needSeq != 0u) return;   // the whole batch is redone sequentially
     const uint32_t n = min(*A.deferCount, A.deferCap);
-    constexpr int PITCH = FXG_CAP + 4;
     float *bucket = reinterpret_cast<float *>(lds);
-    const float *bX = bucket, *bY = bucket + PITCH, *bZ = bucket + 2 * PITCH, *bI = bucket + 3 * PITCH;
-    uint32_t *paint = reinterpret_cast<uint32_t *>(bucket + 4 * PITCH);
+    const uint32_t *bIdx = reinterpret_cast<const uint32_t *>(lds);          // FXG_CAP + 8 photon indices
+    uint32_t *paint = reinterpret_cast<uint32_t *>(lds) + (FXG_CAP + 8);
     uint32_t *hist = paint + PAINT_CAP;   // [16 words][64 lanes]
     Gather G;                             // the slow path's candidate lists alias the bucket (never live together)
     G.cap = S.candCap; G.cd = bucket; G.ci = reinterpret_cast<uint32_t *>(bucket + S.candCap); G.paint = paint;
@@ -98,7 +133,25 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
     const f4 X4 = ld4(S.cieX, q), Y4 = ld4(S.cieY, q), Z4 = ld4(S.cieZ, q);
     WaveCounters wc = {};
     typedef const __attribute__((address_space(4))) nf4 cf4;
-    float carry = 0.f;
+    cf4 *posRows = (cf4 *)gv.pos4;   // positions come through the scalar cache: every lane looks at the same photon
+#ifdef PVOL_FXG_TIME
+    unsigned long long cyProbe = 0, cyStage = 0, cySel = 0, cyFlux = 0, cySlow = 0, nRuns = 0, nSkipped = 0;
+    const unsigned long long tK0 = stamp();
+#define FXG_T(var) var += stamp() - tS; tS = stamp();
+#else
+#define FXG_T(var)
+#endif
+    unsigned long long nStagings = 0, nWrap = 0, nCrowded = 0, nTries = 0;   // diag[2..5]
+    // the eight photons bucket[i .. i+8): indices out of LDS (one address for the wave), positions as scalar loads
+#define FXG_FETCH8(i)                                                                                                         \
+    uint32_t id_[8];                                                                                                          \
+    nf4 P_[8];                                                                                                                \
+    {                                                                                                                         \
+        const uint4 ia = *reinterpret_cast<const uint4 *>(bIdx + (i)), ib = *reinterpret_cast<const uint4 *>(bIdx + (i) + 4); \
+        const uint32_t iv[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};                                              \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) id_[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)iv[u]);         \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u) P_[u] = posRows[id_[u]];                                                \
+    }
     for (uint32_t r0 = blockIdx.x * (uint32_t)LANES; r0 < n; r0 += gridDim.x * (uint32_t)LANES) {
         const uint32_t e = r0 + (uint32_t)lane;
         DeferRec r;
@@ -113,75 +166,78 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
         int nFound = 0;
         bool served = false;      // acc / distSq / nFound hold this lane's lookup
         float Twant = 0.f;
+        float Tlo = 0.f, Thi = INFINITY;   // largest radius^2 seen to hold fewer than nused photons / smallest whose bucket overflowed
         int tries = 0;
         unsigned long long pending = __ballot(valid), slow = 0ull;
-        bool alone = false, probed = false;
-        int shrinks = 0;
-        float Trun = carry > 0.f ? carry : S.rkEstimate;
+        float Trun;
+#ifdef PVOL_FXG_TIME
+        unsigned long long tS = stamp();
+        if (!fxg_compact(gv, S, valid, p, lane, &Trun)) { FXG_T(cyProbe) ++nSkipped; continue; }
+        FXG_T(cyProbe) ++nRuns;
+#else
+        if (!fxg_compact(gv, S, valid, p, lane, &Trun)) continue;   // empty, or scattered: li_fixup_kernel's
+#endif
+        // the probe aims at 1.4 nused photons; the bucket holds eight times nused, and a ball that turns out too small costs a
+        // second staging: start at about twice the probe's volume
+        if (valid) Twant = fminf(S.maxDistSq, Trun * 1.3f);
+        int reprobes = 0;
         while (pending) {
             const bool waiting = ((pending >> lane) & 1ull) != 0ull;
             const int piv = __ffsll((long long)pending) - 1;
             const V3 c = v3(lane_f(p.x, piv), lane_f(p.y, piv), lane_f(p.z, piv));
-            if (!probed) {
-                // ---- first radius of the run: the ball that should hold ~1.4 nused photons at the density around the pivot
-                float T = fminf(Trun, S.maxDistSq);
-                for (int it = 0; it < 4; ++it) {
-                    float vol;
-                    const uint32_t cnt = box_count(gv, c, sqrtf(T), lane, &vol);
-                    const float pred = (float)cnt * (4.18879020478639f * T * sqrtf(T)) / vol;   // photons in the ball at the cube's density
-                    const float want = 1.4f * (float)k;
-                    if (pred >= 1.15f * (float)k && pred <= 2.0f * (float)k) break;
-                    if (pred < (float)k && T >= S.maxDistSq) break;
-                    const float ratio = want / fmaxf(pred, 0.05f * want);   // at most 20x the volume per probe
-                    T = fminf(S.maxDistSq, T * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf(ratio)));
-                }
-                Trun = T;
-                probed = true;
-                if (valid && tries == 0) Twant = Trun;
-            }
-            // ---- cluster: the waiting lookups within a quarter radius of the pivot (all 64 of a group-step, usually)
+            // ---- cluster: the waiting lookups within half a radius of the pivot (all of a compact run, the first time)
             const float Tp = lane_f(Twant, piv);
             const float dPiv = len(p - c);
-            const bool in = waiting && (alone ? lane == piv : dPiv <= 0.25f * sqrtf(Tp));
+            const bool in = waiting && dPiv <= 0.5f * sqrtf(Tp);
             const float Tmax = wave_max(in ? Twant : 0.f);
             const float spread = wave_max(in ? dPiv : 0.f);
             const float Rs = (sqrtf(Tmax) + spread) * 1.0001f + 1e-6f;
             unsigned long long tst = 0;
             __syncthreads();
-            const int Mb = stage_bucket_g<FXG_CAP>(gv, G, bucket, c, Rs, lane, tst);
+            const int Mb = stage_bucket_g<FXG_CAP, true, true>(gv, G, bucket, c, Rs, lane, tst);
+            ++nStagings;
+            FXG_T(cyStage)
             if (Mb < 0) {
-                if (!alone) { alone = true; continue; }   // first the pivot on its own
-                alone = false;
-                // the pivot's own ball overflows the bucket.  A radius that only the probe chose can shrink (half the volume for
-                // everyone still at it; a ball that turns out too small grows again below); one that grew because the lane
-                // counted too few is what the lookup needs: the exact pass takes it.
-                if (lane_i(tries, piv) == 0 && shrinks < 8) {
-                    ++shrinks;
-                    if (waiting && tries == 0) Twant = fminf(Twant, Tp * 0.62996f);
-                    continue;
+                // more photons around the cluster than the bucket holds: smaller balls for all of it -- between the largest radius
+                // seen to hold too few and this one for a lane that has been there, else half the volume
+                // (a run whose first point lies beside the beam the others are in was probed at the wrong place: probe again here)
+                float Tprobe2 = INFINITY;
+                if (reprobes < 3) { ++reprobes; Tprobe2 = 1.3f * probe_radius(gv, c, Tp * 0.5f, k, S.maxDistSq, lane); }
+                bool toSlowO = false;
+                if (in) {
+                    ++tries;
+                    Thi = fminf(Thi, Twant);
+                    Twant = Tlo > 0.f ? sqrtf(Tlo * Thi) : fminf(Twant * 0.62996f, Tprobe2);
+                    // beside a beam the lane's own ball holds few photons while the cluster's (radius + spread) already reaches the
+                    // core: no radius serves both -- the wave-per-lookup pass looks at the lane's ball alone
+                    if (tries >= FXG_TRIES || (Tlo > 0.f && Thi < 1.25f * Tlo)) toSlowO = true;
                 }
-                slow |= 1ull << piv; pending &= ~(1ull << piv);
+#ifdef PVOL_FXG_DEBUG
+                { const int trp = lane_i(tries, piv); const float tl = lane_f(Tlo, piv), th = lane_f(Thi, piv), tw = lane_f(Twant, piv);
+                    if (lane == 0 && trp >= 8 && atomicAdd(&A.counters->pad, 1ull) < 80ull) printf("fxg: OVERFLOW blk %d run %u piv %d Tp %g -> %g Tlo %g Thi %g tries %d in %016llx spread %g probe2 %g\n", (int)blockIdx.x, r0, piv, (double)Tp, (double)tw, (double)tl, (double)th, trp, __ballot(in), (double)spread, (double)Tprobe2); }
+#endif
+                const unsigned long long ts = __ballot(toSlowO);
+                nTries += (unsigned long long)__popcll(ts);
+                slow |= ts; pending &= ~ts;
                 continue;
             }
-            alone = false;
             // ---- A: in-range count and 64-bin histogram of this lane's DistanceSquared values
             const float Tl = Twant;
             const float scale = in ? 64.f / Tl : 0.f;
-            const nf4 px4 = {p.x, p.x, p.x, p.x}, py4 = {p.y, p.y, p.y, p.y}, pz4 = {p.z, p.z, p.z, p.z};
             fxg_clear(hist, lane);
             __syncthreads();
             int nIn = 0;
             float maxIn = 0.f;
-            for (int i = 0; i < Mb; i += 4) {
-                const nf4 dx = *reinterpret_cast<const nf4 *>(bX + i) - px4, dy = *reinterpret_cast<const nf4 *>(bY + i) - py4,
-                          dz = *reinterpret_cast<const nf4 *>(bZ + i) - pz4;
-                const nf4 dd = dx * dx + dy * dy + dz * dz;   // DistanceSquared(photon.p, p), kdtree.h:180
+            for (int i = 0; i < Mb; i += 8) {
+                FXG_FETCH8(i)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool inside = in && dd[u] < Tl;
+                for (int u = 0; u < 8; ++u) {
+                    const float dx = P_[u].x - p.x, dy = P_[u].y - p.y, dz = P_[u].z - p.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;   // DistanceSquared(photon.p, p), kdtree.h:180
+                    const bool inside = in && (i + u < Mb) && d2 < Tl;
                     nIn += inside ? 1 : 0;
-                    maxIn = inside ? fmaxf(maxIn, dd[u]) : maxIn;
-                    const uint32_t bin = (uint32_t)fminf(dd[u] * scale, 63.f);   // fminf also absorbs the sentinels' inf
+                    maxIn = inside ? fmaxf(maxIn, d2) : maxIn;
+                    const uint32_t bin = (uint32_t)fminf(d2 * scale, 63.f);
                     atomicAdd(&hist[(bin >> 2) * LANES + lane], inside ? 1u << ((bin & 3u) << 3) : 0u);
                 }
             }
@@ -191,25 +247,24 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             int tieQuota = 0;
             uint32_t bstar = 0u, below = 0u, inBin = 0u, total = 0u;
             const bool full = in && nIn >= k;
-            if (in && !full) {
-                if (Tl >= S.maxDistSq) { ok = true; }   // fewer than nused within maxdist: all of them (photonvolume.cpp:83 decides on the count)
-            }
+            if (in && !full && Tl >= S.maxDistSq) ok = true;   // fewer than nused within maxdist: all of them (photonvolume.cpp:83 decides on the count)
             if (__ballot(full)) {
                 const bool f1 = fxg_scan(hist, lane, (uint32_t)k, &bstar, &below, &inBin, &total);
                 if (full && (!f1 || total != (uint32_t)nIn)) toSlow = true;   // a byte wrapped
+                nWrap += (unsigned long long)__popcll(__ballot(toSlow));
                 // ---- B: 64 sub-bins of the bin that holds the k-th
                 const bool selB = full && !toSlow;
                 const float fb = (float)bstar;
                 fxg_clear(hist, lane);
                 __syncthreads();
-                for (int i = 0; i < Mb; i += 4) {
-                    const nf4 dx = *reinterpret_cast<const nf4 *>(bX + i) - px4, dy = *reinterpret_cast<const nf4 *>(bY + i) - py4,
-                              dz = *reinterpret_cast<const nf4 *>(bZ + i) - pz4;
-                    const nf4 dd = dx * dx + dy * dy + dz * dz;
+                for (int i = 0; i < Mb; i += 8) {
+                    FXG_FETCH8(i)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float f = dd[u] * scale;
-                        const bool hitB = selB && dd[u] < Tl && (uint32_t)fminf(f, 63.f) == bstar;
+                    for (int u = 0; u < 8; ++u) {
+                        const float dx = P_[u].x - p.x, dy = P_[u].y - p.y, dz = P_[u].z - p.z;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const float f = d2 * scale;
+                        const bool hitB = selB && (i + u < Mb) && d2 < Tl && (uint32_t)fminf(f, 63.f) == bstar;
                         const uint32_t sub = (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f);
                         atomicAdd(&hist[(sub >> 2) * LANES + lane], hitB ? 1u << ((sub & 3u) << 3) : 0u);
                     }
@@ -219,21 +274,23 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                 const uint32_t need1 = (uint32_t)k - below;   // rank of the k-th inside its bin, >= 1
                 const bool f2 = fxg_scan(hist, lane, need1, &sstar, &below2, &inSub, &total2);
                 if (selB && (!f2 || total2 != inBin || inSub > (uint32_t)FXG_MINI)) toSlow = true;
+                nCrowded += (unsigned long long)__popcll(__ballot(selB && toSlow));
                 // ---- C: the members of that sub-bin, ordered
                 const bool selC = selB && !toSlow;
                 float mini[FXG_MINI];
 #pragma unroll
                 for (int m = 0; m < FXG_MINI; ++m) mini[m] = INFINITY;
-                for (int i = 0; i < Mb; i += 4) {
-                    const nf4 dx = *reinterpret_cast<const nf4 *>(bX + i) - px4, dy = *reinterpret_cast<const nf4 *>(bY + i) - py4,
-                              dz = *reinterpret_cast<const nf4 *>(bZ + i) - pz4;
-                    const nf4 dd = dx * dx + dy * dy + dz * dz;
+                for (int i = 0; i < Mb; i += 8) {
+                    FXG_FETCH8(i)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float f = dd[u] * scale;
-                        const bool hitC = selC && dd[u] < Tl && (uint32_t)fminf(f, 63.f) == bstar && (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f) == sstar;
+                    for (int u = 0; u < 8; ++u) {
+                        const float dx = P_[u].x - p.x, dy = P_[u].y - p.y, dz = P_[u].z - p.z;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const float f = d2 * scale;
+                        const bool hitC = selC && (i + u < Mb) && d2 < Tl && (uint32_t)fminf(f, 63.f) == bstar &&
+                                          (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f) == sstar;
                         if (__ballot(hitC)) {
-                            float v = hitC ? dd[u] : INFINITY;   // insertion into the ascending list
+                            float v = hitC ? d2 : INFINITY;   // insertion into the ascending list
 #pragma unroll
                             for (int m = 0; m < FXG_MINI; ++m) { const float lo = fminf(mini[m], v); v = fmaxf(mini[m], v); mini[m] = lo; }
                         }
@@ -252,27 +309,32 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                     ok = true;
                 }
             }
+            FXG_T(cySel)
             // ---- D: flux of the members
             const bool doFlux = ok && (full || nIn >= 10);
             if (__ballot(doFlux)) {
                 int tq = tieQuota;
-                for (int i = 0; i < Mb; ++i) {
-                    const float dx = bX[i] - p.x, dy = bY[i] - p.y, dz = bZ[i] - p.z;
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-                    bool mem = doFlux && d2 < Tl && d2 < kth;
-                    if (doFlux && d2 == kth && tq > 0) { mem = true; --tq; }
-                    if (!__ballot(mem)) continue;
-                    const uint32_t pidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[i]));
-                    const float wgt = mem ? wIso : 0.f;
-                    cf4 *row = (cf4 *)(S.alpha4 + (size_t)pidx * 8);
+                for (int i = 0; i < Mb; i += 8) {
+                    FXG_FETCH8(i)
 #pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) {
-                        const nf4 rr = row[qq];
-                        acc[4 * qq] = __builtin_fmaf(rr.x, wgt, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rr.y, wgt, acc[4 * qq + 1]);
-                        acc[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, acc[4 * qq + 3]);
+                    for (int u = 0; u < 8; ++u) {
+                        const float dx = P_[u].x - p.x, dy = P_[u].y - p.y, dz = P_[u].z - p.z;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        bool mem = doFlux && (i + u < Mb) && d2 < Tl && d2 < kth;
+                        if (doFlux && (i + u < Mb) && d2 == kth && tq > 0) { mem = true; --tq; }
+                        if (!__ballot(mem)) continue;
+                        const float wgt = mem ? wIso : 0.f;
+                        cf4 *row = (cf4 *)(S.alpha4 + (size_t)id_[u] * 8);
+#pragma unroll
+                        for (int qq = 0; qq < 8; ++qq) {
+                            const nf4 rr = row[qq];
+                            acc[4 * qq] = __builtin_fmaf(rr.x, wgt, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rr.y, wgt, acc[4 * qq + 1]);
+                            acc[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, acc[4 * qq + 3]);
+                        }
                     }
                 }
             }
+            FXG_T(cyFlux)
             if (ok) {
                 served = true;
                 nFound = full ? k : nIn;
@@ -282,19 +344,22 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             const bool failed = in && !ok && !toSlow;   // fewer than nused inside a ball smaller than maxdist
             if (failed) {
                 ++tries;
+                Tlo = Tl;
                 const float grow = nIn > 0 ? 1.35f * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf((float)k / (float)nIn)) : 8.f;
-                Twant = fminf(S.maxDistSq, Twant * fmaxf(1.5f, grow));
-                if (tries >= 3) toSlow = true;
+                const float Tg = fminf(S.maxDistSq, Tl * fmaxf(1.5f, grow));
+                Twant = Tg < Thi ? Tg : sqrtf(Tlo * Thi);   // never back into a ball whose bucket overflowed
+                if (tries >= FXG_TRIES || Thi < 1.25f * Tlo) toSlow = true;
             }
+#ifdef PVOL_FXG_DEBUG
+            { const unsigned long long fl = __ballot(failed && tries >= 8); if (fl) { const int j = __ffsll((long long)fl) - 1;
+                const float tl = lane_f(Tl, j), tw = lane_f(Twant, j), th = lane_f(Thi, j); const int ni = lane_i(nIn, j), trj = lane_i(tries, j);
+                if (lane == 0 && atomicAdd(&A.counters->pad, 1ull) < 80ull) printf("fxg: FAILED blk %d run %u lane %d Tl %g nIn %d -> Twant %g Thi %g tries %d Mb %d\n", (int)blockIdx.x, r0, j, (double)tl, ni, (double)tw, (double)th, trj, Mb); } }
+#endif
+            nTries += (unsigned long long)__popcll(__ballot(failed && toSlow));
             slow |= __ballot(toSlow);
             pending &= ~__ballot(ok || toSlow);
         }
         { const unsigned long long sv = __ballot(served); if (lane == 0 && sv) atomicAdd(&A.counters->diag[1], (unsigned long long)__popcll(sv)); }   // lookups served from shared buckets
-        // ---- what the next run starts its probe from
-        {
-            const float m = wave_max(served && nFound >= k ? distSq : 0.f);
-            carry = m > 0.f ? m : S.maxDistSq;
-        }
         // ---- terms of the lanes served above:  exp(-sigma_t R_j) sigma_s step albedo L_ii,  L_ii = sum(alpha) phase / (4/3 pi r^3 sigma_s(p))
         if (served && nFound >= 10) {
             const float dV = distSq * sqrtf(distSq);
@@ -320,6 +385,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             }
         }
         // ---- the exact pass for what is left (one wave-cooperative lookup each)
+        FXG_T(cySel)
         while (slow) {
             const int j = __ffsll((long long)slow) - 1;
             slow &= slow - 1ull;
@@ -328,8 +394,8 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             const uint32_t ray = (uint32_t)lane_i((int)r.ray, j);
             float rk;
             __syncthreads();
-            const f4 Lii = lphoton<false, 12>(S, G, v3(0.f, 0.f, 1.f), pj, sigS4 * dens, lane, wc, carry < S.maxDistSq ? carry : 0.f, &rk);
-            if (rk > 0.f) carry = rk;
+            const float Tj = lane_f(Twant, j);   // what the lane last asked for (lphoton widens its first radius by 1.3 and grows it when it fails)
+            const f4 Lii = lphoton<false, 12, true>(S, G, v3(0.f, 0.f, 1.f), pj, sigS4 * dens, lane, wc, Tj < S.maxDistSq ? Tj : 0.f, &rk);
             const f4 kk = sigT4 * kRem;
             f4 c = make_float4(__builtin_amdgcn_exp2f(kk.x), __builtin_amdgcn_exp2f(kk.y), __builtin_amdgcn_exp2f(kk.z), __builtin_amdgcn_exp2f(kk.w));
             c = clean4(c * (sigS4 * (albedo4 * Lii) * stepD), q);
@@ -352,11 +418,26 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             }
             if (lane == 0) atomicAdd(&A.counters->diag[0], 1ull);   // exact-pass lookups (reported with the stats)
         }
+        FXG_T(cySlow)
+    }
+#undef FXG_FETCH8
+#ifdef PVOL_FXG_TIME
+    if (lane == 0) {
+        atomicAdd(&A.counters->cySearch, cyStage); atomicAdd(&A.counters->cySelect, cySel); atomicAdd(&A.counters->cyFlux, cyFlux);
+        atomicAdd(&A.counters->cyTotal, stamp() - tK0); atomicAdd(&A.counters->nTested, cyProbe); atomicAdd(&A.counters->nKept, cySlow);
+        atomicAdd(&A.counters->nLookupsLt10, nRuns); atomicAdd(&A.counters->nShadowUnoccluded, nSkipped);
+    }
+#endif
+    if (lane == 0) {
+        if (nStagings) atomicAdd(&A.counters->diag[2], nStagings);
+        if (nWrap) atomicAdd(&A.counters->diag[3], nWrap);
+        if (nCrowded) atomicAdd(&A.counters->diag[4], nCrowded);
+        if (nTries) atomicAdd(&A.counters->diag[5], nTries);
     }
 }
 
 extern "C" size_t pvol_fixgrp_lds_bytes(int candCap) {
-    const size_t bucket = (size_t)(FXG_CAP + 4) * 16;
+    const size_t bucket = (size_t)(FXG_CAP + 8) * 4;
     return std::max(bucket, (size_t)candCap * 8) + PAINT_CAP * 4 + 16 * LANES * 4;
 }
 #endif

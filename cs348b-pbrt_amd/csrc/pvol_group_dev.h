@@ -75,56 +75,18 @@ __device__ float grid_tau_lane(const DevScene &S, V3 o, V3 d, float mint, float 
     return dsum * stepSize;
 }
 
-// A photon grid as the staging code sees it (the volume map of DevScene, or the caustic map of DevSurface)
-struct GridView {
-    float cellSize, invCell;
-    float gridLo[3];
-    int32_t gdim[3];
-    const uint32_t *cellStart;
-    const float4 *pos4;
-};
-__device__ __forceinline__ GridView volume_grid(const DevScene &S) {
-    GridView g;
-    g.cellSize = S.cellSize; g.invCell = S.invCell;
-    for (int i = 0; i < 3; ++i) { g.gridLo[i] = S.gridLo[i]; g.gdim[i] = S.gdim[i]; }
-    g.cellStart = S.cellStart; g.pos4 = S.pos4;
-    return g;
-}
-
 // Photons within Rs of c -> LDS bucket of CAP slots (SoA, pitch CAP + 4).  Returns the count, or -1 if the bucket would overflow.
-template <int CAP>
+// IDX_ONLY: the bucket is the list of photon indices alone (CAP + 8 words, padded with index 0 to a multiple of eight).
+template <int CAP, bool FINE = false, bool IDX_ONLY = false>
 __device__ int stage_bucket_g(const GridView &S, Gather &G, float *bucket, V3 c, float Rs, int lane, unsigned long long &tested) {
     constexpr int GRP_PITCH_ = CAP + 4;
-    float *bX = bucket, *bY = bucket + GRP_PITCH_, *bZ = bucket + 2 * GRP_PITCH_, *bI = bucket + 3 * GRP_PITCH_;
-    const float cell = S.cellSize, inv = S.invCell;
-    const float eps = cell * 1e-4f;
+    float *bX = bucket, *bY = bucket + GRP_PITCH_, *bZ = bucket + 2 * GRP_PITCH_, *bI = IDX_ONLY ? bucket : bucket + 3 * GRP_PITCH_;
     const float T = Rs * Rs;
-    const int cy = (int)floorf((c.y - S.gridLo[1]) * inv), cz = (int)floorf((c.z - S.gridLo[2]) * inv);
-    const int Rt = (int)ceilf(Rs * inv + 1e-3f);
-    const int side = 2 * Rt + 1, nrows = side * side;
+    const GridRows rows = grid_rows<FINE>(S, c, Rs, 0);
     int count = 0;
-    for (int rb = 0; rb < nrows; rb += LANES) {
-        int r = rb + lane;
-        int iy = r / side;
-        int dy = iy - Rt, dz = (r - iy * side) - Rt;
-        int y = cy + dy, z = cz + dz;
-        bool rowOn = r < nrows && y >= 0 && y < S.gdim[1] && z >= 0 && z < S.gdim[2];
-        float ylo = S.gridLo[1] + y * cell, zlo = S.gridLo[2] + z * cell;
-        float ddy = fmaxf(0.f, fmaxf(ylo - c.y, c.y - (ylo + cell)) - eps);
-        float ddz = fmaxf(0.f, fmaxf(zlo - c.z, c.z - (zlo + cell)) - eps);
-        float rd2 = ddy * ddy + ddz * ddz;
-        rowOn = rowOn && rd2 < T;
-        float hw = sqrtf(fmaxf(0.f, T - rd2)) + eps;
-        int x0 = (int)floorf((c.x - hw - S.gridLo[0]) * inv), x1 = (int)floorf((c.x + hw - S.gridLo[0]) * inv);
-        x0 = max(x0, 0);
-        x1 = min(x1, S.gdim[0] - 1);
-        rowOn = rowOn && x0 <= x1;
-        uint32_t start = 0u, rlen = 0u;
-        if (rowOn) {
-            size_t base = ((size_t)z * S.gdim[1] + y) * S.gdim[0];
-            start = S.cellStart[base + x0];
-            rlen = S.cellStart[base + x1 + 1] - start;
-        }
+    for (int rb = 0; rb < rows.nrows; rb += LANES) {
+        uint32_t start, rlen;
+        grid_row_range<FINE>(S, rows, rb + lane, c, T, &start, &rlen);
         const uint32_t lenS = rlen <= PAINT_ROW ? rlen : 0u;
         uint32_t incl = lenS;
         incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
@@ -178,7 +140,8 @@ __device__ int stage_bucket_g(const GridView &S, Gather &G, float *bucket, V3 c,
                         if (count + add > CAP) return -1;
                         if (acc) {
                             const int at = count + (int)lanes_below(m, lane);
-                            bX[at] = P[k].x; bY[at] = P[k].y; bZ[at] = P[k].z; bI[at] = __uint_as_float(I[k]);
+                            if (!IDX_ONLY) { bX[at] = P[k].x; bY[at] = P[k].y; bZ[at] = P[k].z; }
+                            bI[at] = __uint_as_float(I[k]);
                         }
                         count += add;
                     }
@@ -193,7 +156,8 @@ __device__ int stage_bucket_g(const GridView &S, Gather &G, float *bucket, V3 c,
             tested += segLen;
         }
     }
-    if (lane < 4) { bX[count + lane] = 3.0e18f; bY[count + lane] = 3.0e18f; bZ[count + lane] = 3.0e18f; bI[count + lane] = 0.f; }   // pad to a multiple of four: never inside any radius
+    if (IDX_ONLY) { if (lane < 8) bI[count + lane] = 0.f; }
+    else if (lane < 4) { bX[count + lane] = 3.0e18f; bY[count + lane] = 3.0e18f; bZ[count + lane] = 3.0e18f; bI[count + lane] = 0.f; }   // pad to a multiple of four: never inside any radius
     __syncthreads();
     return count;
 }
@@ -885,6 +849,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
 
+#include "pvol_fixgrp_dev.h"   // li_fixup_group_kernel: the hand-over list of nused beyond the bucket plan, 64 lookups per staged bucket
+
 // The lookups li_group_kernel handed over: one wave per entry runs the exact wave-cooperative lphoton() and adds the
 // entry's term  exp(-sigma_t R_j) sigma_s step albedo L_ii  to the ray's output (atomic: a ray can have several entries).
 template <bool STATS, bool SPECTRAL, int NREG>
@@ -911,14 +877,29 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     // An entry without a guess of its own (nused beyond the bucket plan hands everything over unseen) would otherwise scan the
     // whole maxdist ball -- tens of thousands of photons inside pinkfloyd's beams.  A wrong first radius costs a retry, never
     // the result: lphoton() widens it until the k nearest are inside.
+    // With A.fixGroup the list comes in padded 64-slot runs and li_fixup_group_kernel serves the compact ones (fxg_compact).
     float carry = 0.f;
-    for (uint32_t e0 = blockIdx.x * 64u; e0 < n; e0 += gridDim.x * 64u)
-    for (uint32_t e = e0; e < min(e0 + 64u, n); ++e) {
-        const DeferRec r = A.defer[e];
-        if (r.ray == 0xffffffffu) continue;   // padding of a 64-slot run
+    const GridView gv = volume_grid(S);
+    for (uint32_t e0 = blockIdx.x * 64u; e0 < n; e0 += gridDim.x * 64u) {
+    DeferRec mine;
+    mine.ray = 0xffffffffu; mine.px = mine.py = mine.pz = 0.f; mine.kRem = 0.f; mine.stepD = 0.f; mine.guess = 0.f; mine.dens = 1.f;
+    if (e0 + (uint32_t)lane < n) mine = A.defer[e0 + lane];
+    unsigned long long todo = __ballot(mine.ray != 0xffffffffu);
+    if (A.fixGroup) {
+        float Tprobe;
+        if (fxg_compact(gv, S, mine.ray != 0xffffffffu, v3(mine.px, mine.py, mine.pz), lane, &Tprobe)) continue;
+        if (Tprobe > 0.f) carry = Tprobe * (1.f / PVOL_GUESS_SCALE);
+    }
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        DeferRec r;
+        r.ray = (uint32_t)lane_i((int)mine.ray, j);
+        r.px = lane_f(mine.px, j); r.py = lane_f(mine.py, j); r.pz = lane_f(mine.pz, j);
+        r.kRem = lane_f(mine.kRem, j); r.stepD = lane_f(mine.stepD, j); r.guess = lane_f(mine.guess, j); r.dens = lane_f(mine.dens, j);
         float rk;
         const float first = r.guess > 0.f ? r.guess : (carry > 0.f ? carry : S.rkEstimate);
-        const f4 Lii = lphoton<STATS, NREG>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4 * r.dens, lane, wc, first, &rk);   // g == 0: the direction is not read
+        const f4 Lii = lphoton<STATS, NREG, true>(S, G, v3(0.f, 0.f, 1.f), v3(r.px, r.py, r.pz), sigS4 * r.dens, lane, wc, first, &rk);   // g == 0: the direction is not read
         carry = rk > 0.f ? rk : S.maxDistSq;   // fewer than nused within maxdist: sparse here, the full ball is the cheap radius
         const f4 kk = sigT4 * r.kRem;
         f4 c = make_float4(__builtin_amdgcn_exp2f(kk.x), __builtin_amdgcn_exp2f(kk.y), __builtin_amdgcn_exp2f(kk.z), __builtin_amdgcn_exp2f(kk.w));
@@ -941,12 +922,11 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
             }
         }
     }
+    }
     wc.rays = 0; wc.steps = 0;   // the march steps were counted by li_group_kernel
     if (STATS) { wc.diag2 = stamp() - tk0; wc.cySearch = wc.cySelect = wc.cyFlux = 0; tk0 = stamp(); }   // this kernel's cycles are reported on their own
     flush_counters<STATS>(A.counters, wc, tk0, lane);
 }
-
-#include "pvol_fixgrp_dev.h"   // li_fixup_group_kernel: the hand-over list of nused beyond the bucket plan, 64 lookups per staged bucket
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;
@@ -964,8 +944,8 @@ extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, 
     const bool fixGroup = args->fixGroup != 0 && big && !stats;
     const size_t fixGrpLds = pvol_fixgrp_lds_bytes(candCap);
 #define GRP_LAUNCH(ST, SP, RP, GR) hipLaunchKernelGGL((li_group_kernel<ST, SP, RP, GR>), grid, block, ldsBytes, stream, *args)
-#define FIX_LAUNCH(ST, SP) do { if (fixGroup) hipLaunchKernelGGL((li_fixup_group_kernel<SP>), fgrid, block, fixGrpLds, stream, *args); \
-                                else if (big) hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 12>), fgrid, block, fixLds, stream, *args); \
+#define FIX_LAUNCH(ST, SP) do { if (fixGroup) hipLaunchKernelGGL((li_fixup_group_kernel<SP>), fgrid, block, fixGrpLds, stream, *args);   /* compact runs */ \
+                                if (big) hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 12>), fgrid, block, fixLds, stream, *args); \
                                 else hipLaunchKernelGGL((li_fixup_kernel<ST, SP, 4>), fgrid, block, fixLds, stream, *args); } while (0)
     if (replay == 0) {
         if (stats) { if (spectral) { GRP_LAUNCH(true, true, false, false); FIX_LAUNCH(true, true); } else { GRP_LAUNCH(true, false, false, false); FIX_LAUNCH(true, false); } }

@@ -40,6 +40,7 @@ struct GridBuildArgs {
     float lo[3];
     float inv;
     int32_t gdim[3];
+    int32_t sub;
     int32_t volKind;
     float extLo[3], extHi[3];
     float w2v[16];
@@ -56,7 +57,8 @@ extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused, in
 extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
-                                      uint32_t *cellStart, hipStream_t stream);
+                                      uint32_t *cellStart, uint32_t *subStart, hipStream_t stream);
+extern "C" hipError_t pvol_grid_occupancy(const uint32_t *cellStart, uint32_t ncells, double *sumSquares, hipStream_t stream);
 
 struct pvol_ctx {
     pvol_params params;
@@ -69,6 +71,7 @@ struct pvol_ctx {
     float *dRawP, *dRawWi, *dRawAlpha;  // upload order (kept for pvol_download_photons)
     float4 *dPos4, *dAlpha4, *dWi4;
     uint32_t *dCellStart;
+    uint32_t *dSubStart = 0;   // second level of a clumpy map (pvol_grid.hip), else 0
     DevCounters *dCounters;
     uint32_t *dWords;   // [0] chunk counter of the ray-parallel kernels, [1] needSeq flag, [2] length of the deferred-lookup list, [3] chunk counter of a gated backup kernel
     DeferRec *dDefer = 0;   // li_group_kernel's deferred lookups (grown on demand)

@@ -42,6 +42,7 @@
 #endif
 
 #include "pvol_rng_dev.h"
+#include "pvol_gridrows_dev.h"
 
 // ------------------------------------------------------------------------------------------ k-NN gather
 struct Gather {
@@ -117,17 +118,15 @@ __device__ float select_k(Gather &G, int M, int k, float T, int lane) {
 // returns total flux / (4/3 pi r^3 sigma_s) in the float4 layout, or 0 when fewer than 10 are found.
 // `guess` (> 0) is a previous k-th distance^2 at a nearby point; `rkOut` returns this lookup's
 // (0 when fewer than k photons lie within maxDist).
-template <bool STATS, int NREG>
+template <bool STATS, int NREG, bool FINE = false>
 __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, int lane, WaveCounters &wc, float guess, float *rkOut) {
     const int q = lane & 7;
     f4 zero = mk4(0.f);
     *rkOut = 0.f;
     if (S.nPhotons == 0u) return zero;
-    const float cell = S.cellSize, inv = S.invCell;
-    const float eps = cell * 1e-4f;  // slack on the PRUNING bounds only; acceptance stays the exact d2 < T
+    const GridView gv = volume_grid(S);
     const int k = S.nUsed;
     unsigned long long tested = 0;
-    const int cy = (int)floorf((pt.y - S.gridLo[1]) * inv), cz = (int)floorf((pt.z - S.gridLo[2]) * inv);
     float T = S.maxDistSq;
     bool guessed = false;
     if (guess > 0.f) {
@@ -139,31 +138,10 @@ __device__ f4 lphoton(const DevScene &S, Gather &G, V3 w, V3 pt, f4 sigS_at_p, i
     if (STATS) t0s = stamp();
     for (;;) {
         count = 0;
-        int Rt = min(S.ringMax, (int)ceilf(sqrtf(T) * inv + 1e-3f));
-        const int side = 2 * Rt + 1, nrows = side * side;
-        const int sideRcp = 65536 / side + 1;   // r / side == (r * sideRcp) >> 16 for r < side^2 + 64, side <= 17
-        for (int rb = 0; rb < nrows; rb += LANES) {
-            int r = rb + lane;
-            int iy = (r * sideRcp) >> 16;
-            int dy = iy - Rt, dz = (r - iy * side) - Rt;
-            int y = cy + dy, z = cz + dz;
-            bool rowOn = r < nrows && y >= 0 && y < S.gdim[1] && z >= 0 && z < S.gdim[2];
-            float ylo = S.gridLo[1] + y * cell, zlo = S.gridLo[2] + z * cell;
-            float ddy = fmaxf(0.f, fmaxf(ylo - pt.y, pt.y - (ylo + cell)) - eps);
-            float ddz = fmaxf(0.f, fmaxf(zlo - pt.z, pt.z - (zlo + cell)) - eps);
-            float rd2 = ddy * ddy + ddz * ddz;
-            rowOn = rowOn && rd2 < T;
-            float hw = sqrtf(fmaxf(0.f, T - rd2)) + eps;
-            int x0 = (int)floorf((pt.x - hw - S.gridLo[0]) * inv), x1 = (int)floorf((pt.x + hw - S.gridLo[0]) * inv);
-            x0 = max(x0, 0);
-            x1 = min(x1, S.gdim[0] - 1);
-            rowOn = rowOn && x0 <= x1;
-            uint32_t start = 0u, rlen = 0u;
-            if (rowOn) {
-                size_t base = ((size_t)z * S.gdim[1] + y) * S.gdim[0];
-                start = S.cellStart[base + x0];
-                rlen = S.cellStart[base + x1 + 1] - start;
-            }
+        const GridRows rows = grid_rows<FINE>(gv, pt, sqrtf(T), S.ringMax);
+        for (int rb = 0; rb < rows.nrows; rb += LANES) {
+            uint32_t start, rlen;
+            grid_row_range<FINE>(gv, rows, rb + lane, pt, T, &start, &rlen);
             // ---- short rows (<= PAINT_ROW photons, the usual case): their photon indices are PAINTED into an LDS
             // list in concatenated order -- lane j writes start_j + it at off_j + it -- so that the candidate
             // loop below is one LDS read per 64 candidates instead of a per-lane search for "which row am I in"

@@ -107,7 +107,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     pvol_free_photons(c);
     pvol_free_surface_stores(c);
     DevScene &h = c->hs;
-    h.nPhotons = 0; h.cellStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
+    h.nPhotons = 0; h.cellStart = 0; h.subStart = 0; h.pos4 = 0; h.alpha4 = 0; h.wi4 = 0;
     memset(c->shootStats, 0, sizeof(c->shootStats));
     if (c->hs.nLights == 0) return pvol_push_scene(c);   // photonshooter.cpp:459
     int rc = pvol_push_scene(c);

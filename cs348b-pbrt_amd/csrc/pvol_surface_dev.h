@@ -109,7 +109,7 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
     GridView cg;
     cg.cellSize = S.surf.cellSize; cg.invCell = S.surf.invCell;
     for (int i = 0; i < 3; ++i) { cg.gridLo[i] = S.surf.gridLo[i]; cg.gdim[i] = S.surf.gdim[i]; }
-    cg.cellStart = S.surf.cellStart; cg.pos4 = S.surf.pos4;
+    cg.cellStart = S.surf.cellStart; cg.subStart = 0; cg.pos4 = S.surf.pos4;
     const int k = S.surf.nLookup;
     for (unsigned long long g0 = (unsigned long long)blockIdx.x * LANES; g0 < A.nRays; g0 += (unsigned long long)gridDim.x * LANES) {
         const size_t ri = (size_t)g0 + lane;

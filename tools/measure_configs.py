@@ -124,7 +124,12 @@ def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n
                         "march_kernels_s": kms * nl * 1e-3, "Msamples_per_s_march_kernels": n / (kms * nl) / 1e3,
                         "mean_rgb": float(rgb.mean().item()),
                         # nused beyond the bucket plan (li_fixup_group_kernel): lookups served from shared buckets / by the exact pass
-                        "handed_over_shared_bucket": work["group_plan_skipped"], "handed_over_exact_pass": work["group_guess_failed"]}
+                        "handed_over_shared_bucket": work["group_plan_skipped"], "handed_over_exact_pass": work["group_guess_failed"],
+                        "bucket_stagings": work["cy_fallback"],
+                        "exact_pass_because": { "counter_wrapped": work["group_deferred_overflow"],
+                                               "crowded_sub_bin": work["group_deferred_too_few"], "radius_corrections_exhausted": work["group_attempts"]}}
+        if "--raw-stats" in sys.argv:
+            rec["frame"]["raw_stats"] = work
     pv.close()
     print(json.dumps(rec), flush=True)
 
@@ -145,6 +150,7 @@ if __name__ == "__main__":
     heartbeat()
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     full = "--full" in sys.argv
+    spp_over = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--spp=")]   # reduced frames at another sample count
     if "--no-li" in sys.argv:   # frames only (kernel traces)
         _run = run
         def run(*a, **k):   # noqa: E731,F811
@@ -157,8 +163,8 @@ if __name__ == "__main__":
             frame=(256, 256, 16, True))
     if want("C3"):
         run("C3", "pinkfloyd", 4000000, 256, "config 3: pinkfloyd 1920x1080, 4 M photons, nused 500, two lights, on ONE MI355X; frame at %s" %
-            ("512 spp (stated)" if full else "8 spp instead of 512"), li=(480, 270, 4),
-            frame=(1920, 1080, 512 if full else 8, full), n_caustic_photons=0)
+            ("512 spp (stated)" if full else "%d spp instead of 512" % (spp_over[0] if spp_over else 8)), li=(480, 270, 4),
+            frame=(1920, 1080, 512 if full else (spp_over[0] if spp_over else 8), full), n_caustic_photons=0)
     if want("C4"):
         run("C4", "volumescene_grid16", 2000000, 16384, "config 4: 128^3 VolumeGrid (generated here), 2 M photons; frame 256x256 at %s" %
             ("1024 spp (stated)" if full else "64 spp instead of 1024"), li=(128, 128, 8),

@@ -553,6 +553,24 @@ static int cmdTables(const char *outPath) {
     std::vector<float> sp, spy;
     for (int i = 0; i < 7; ++i) { float rgb[3] = {cols[i], cols[i], cols[i]}; Spectrum s = Spectrum::FromRGB(rgb); putSpec(sp, s); spy.push_back(s.y()); }
     out.putf("rgb.grey", cols, 7); out.putf("rgb.spectra", sp); out.putf("rgb.y", spy);
+    // the Smits tables behind FromRGB (core/spectrum.cpp:699-958, public externs of spectrum.h:77-92), as compiled into the reference,
+    // and FromRGB of some coloured inputs, both kinds (spectrum.cpp:154-241): what the scene-file front end is checked against
+    out.putf("rgb2spect.lambda", RGB2SpectLambda, nRGB2SpectSamples);
+    {
+        const float *refl[7] = {RGBRefl2SpectWhite, RGBRefl2SpectCyan, RGBRefl2SpectMagenta, RGBRefl2SpectYellow, RGBRefl2SpectRed, RGBRefl2SpectGreen, RGBRefl2SpectBlue};
+        const float *illum[7] = {RGBIllum2SpectWhite, RGBIllum2SpectCyan, RGBIllum2SpectMagenta, RGBIllum2SpectYellow, RGBIllum2SpectRed, RGBIllum2SpectGreen, RGBIllum2SpectBlue};
+        std::vector<float> a, b;
+        for (int i = 0; i < 7; ++i) { a.insert(a.end(), refl[i], refl[i] + nRGB2SpectSamples); b.insert(b.end(), illum[i], illum[i] + nRGB2SpectSamples); }
+        out.putf("rgb2spect.refl", a); out.putf("rgb2spect.illum", b);
+        const float rgbs[8][3] = {{.8f, .2f, .1f}, {.1f, .7f, .3f}, {.2f, .3f, .9f}, {.9f, .9f, .1f}, {.05f, .6f, .6f}, {.7f, .1f, .7f}, {1.f, 1.f, 1.f}, {0.f, 0.f, 0.f}};
+        std::vector<float> in, outR, outI;
+        for (int i = 0; i < 8; ++i) {
+            in.insert(in.end(), rgbs[i], rgbs[i] + 3);
+            putSpec(outR, SampledSpectrum::FromRGB(rgbs[i], SPECTRUM_REFLECTANCE));
+            putSpec(outI, SampledSpectrum::FromRGB(rgbs[i], SPECTRUM_ILLUMINANT));
+        }
+        out.putf("rgb.colour_in", in); out.putf("rgb.colour_refl", outR); out.putf("rgb.colour_illum", outI);
+    }
     return out.save(outPath) ? 0 : 1;
 }
 

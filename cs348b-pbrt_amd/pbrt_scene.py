@@ -15,7 +15,7 @@ Arithmetic is float32 in the reference's operation order (Matrix4x4::Mul, Transf
 Gauss-Jordan Inverse of core/transform.cpp:76-135; transforms carry (m, mInv) pairs like core/transform.h so an inverse is the
 product of the analytic inverses, not a numerical inversion), and "color" parameters go through a restatement of
 SampledSpectrum::FromRGB (core/spectrum.cpp:154-241: ParamSet::AddRGBSpectrum converts every colour as a REFLECTANCE) over the
-reference's own tables (data/spectral_tables.bin: captured from the compiled reference by oracle/ref_capture.cpp `tables`).
+reference's own tables (data/spectral_tables.bin: numbers captured from the compiled reference, see tools/make_spectral_tables.py).
 tests/test_pbrt_scene.py holds it against the scenes the reference itself built (tests/golden/scene_*.bin)."""
 import math
 import os

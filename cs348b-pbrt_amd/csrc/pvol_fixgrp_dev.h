@@ -1,11 +1,18 @@
 // pvol_fixgrp_dev.h -- li_fixup_group_kernel: the exact k-nearest lookups li_group_kernel hands over when nused lies beyond its
-// bucket plan (C3: nused 500), one lookup per LANE, 64 neighbouring lookups sharing one staged bucket.
+// bucket plan (C3: nused 500), one lookup per LANE, the 64 neighbouring lookups of a list run sharing one staged bucket.
 //
 // Why: a k = 500 lookup reads 500 photon rows of 128 B.  One wave per lookup (li_fixup_kernel) moves 64 KB per lookup and
 // spends its time on dependent memory round trips; the 64 lookups of a group at one march step (neighbouring rays, same depth)
-// want nearly the same photons, so here the union of their search balls is staged ONCE in LDS, every lane selects its own
-// k nearest out of it, and the flux rows are read once per 64 lookups through the scalar cache.
+// want nearly the same photons, so here the union of their search balls is staged ONCE, every lane selects its own k nearest
+// out of it, and positions and flux rows are read once per 64 lookups through the scalar cache.
 //
+// The list comes in padded 64-slot runs, one per group-step (LiArgs::fixGroup).  fxg_compact() decides from the run alone who
+// serves it: this kernel when the 64 points lie within a quarter of the probed radius of the first one, li_fixup_kernel (a wave
+// per lookup) when they are scattered relative to it -- few samples per pixel inside a dense beam.  Both kernels evaluate the
+// same function; neither writes anything for the other.
+//
+// Bucket: the INDICES of the photons within (radius + spread) of the run's first point, <= FXG_CAP of them in LDS (16 KB).
+// Every lane looks at the same photon at the same time, so its position is a scalar load (eight in flight, FXG_FETCH8).
 // Selection per lane (kdtree.h:157-206 keeps the nused nearest and shrinks maxDistSquared to the farthest of them):
 //   A  histogram of DistanceSquared over the bucket: 64 bins on [0, T_lane), 8-bit counters packed four to an LDS word per
 //      lane (ds_add_u32); a byte that wrapped shows as sum != the exact in-range count and sends the lane to the exact pass
@@ -16,12 +23,13 @@
 // Bins are floor(d2 * 64 / T) and floor(frac * 64): monotone in d2, so every pass narrows the same order statistics; what
 // decides membership in the end is the comparison with the k-th value found in C, never a bin.
 //
-// Runs whose lookups are scattered relative to their radius (fxg_compact) are left to li_fixup_kernel.
-// The first radius^2 of a run comes from a density probe (photon counts of the grid cells around the run's first point, read
-// from the cell-start prefix sums), not from a neighbour's result: runs arrive from all over the frame.  A lane whose ball held
-// fewer than nused photons grows it by what its count says (like lphoton()) and joins a later bucket; one whose own ball
-// overflows the bucket shrinks it (bisecting between the two when it has seen both).  After FXG_TRIES corrections the
-// wave-cooperative lphoton() serves the lookup -- the slow path, exact as well.
+// Radii.  The first radius^2 of a run comes from a density probe (photon counts of the grid cells around the run's first
+// point, read from the cell-start prefix sums), not from a neighbour's result: runs arrive from all over the frame.  A bucket
+// that overflows makes the cluster's balls smaller; a lane whose ball held fewer than nused photons grows it by what its count
+// says (like lphoton()) and joins a later bucket; a lane that has seen both is bisected between them.  After FXG_TRIES
+// corrections, or when that bracket closes below 25 % (a point beside a beam: its own ball nearly empty, the cluster's already in
+// the core), the wave-cooperative lphoton() serves the lookup -- the slow path, exact as well.
+// Instrumented builds: -DPVOL_FXG_TIME (cycle split into the stats counters), -DPVOL_FXG_DEBUG (per-run prints).
 #ifndef PVOL_FIXGRP_DEV_H
 #define PVOL_FIXGRP_DEV_H
 

@@ -592,6 +592,11 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         if (!c->pool.empty()) { ev = c->pool.back(); c->pool.pop_back(); }
         else if (!ok(hipEventCreate(&ev.first)) || !ok(hipEventCreate(&ev.second))) return PVOL_E_NO_DEVICE;
     }
+    // the pair goes back to the pool on every early return below (an UNSUPPORTED batch must not leak events)
+    struct EventReturn {
+        pvol_ctx *c; std::pair<hipEvent_t, hipEvent_t> ev; bool keep = false;
+        ~EventReturn() { if (!keep) { std::lock_guard<std::mutex> g(c->mu); c->pool.push_back(ev); } }
+    } evGuard{c, ev};
     hipError_t e;
     // the tile pre-pass can COUNT Li()'s draws (instead of drawing them) under the same conditions as li_par_kernel,
     // provided no march step can reach the roulette
@@ -726,6 +731,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     {
         std::lock_guard<std::mutex> g(c->mu);
         c->pending.push_back(ev);
+        evGuard.keep = true;
     }
     return ok(e) ? PVOL_OK : PVOL_E_NO_DEVICE;
 }

@@ -129,6 +129,8 @@ void pvol_destroy(pvol_ctx *c) {
     for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (c->dDensity) hipFree(c->dDensity);
+    if (c->dBvhNodes) hipFree(c->dBvhNodes);
+    if (c->dBvhTris) hipFree(c->dBvhTris);
     if (c->dRecords) hipFree(c->dRecords);
     if (c->dState) hipFree(c->dState);
     if (c->dDefer) hipFree(c->dDefer);
@@ -190,8 +192,10 @@ static int fill_shoot_scene(const pvol_ctx *c, const pvol_scene *s, DevShootScen
     for (uint32_t i = 0; i < s->n_triangles; ++i) {
         int mi = s->triangles[i].material;
         if (mi < 0 || (uint32_t)mi >= std::max(1u, s->n_materials)) return PVOL_E_INVALID;
-        H.triMat[i] = mi;
-        H.triFlip[i] = s->triangles[i].flip_normal;
+        if (s->n_triangles <= PVOL_MAX_TRIS) {   // a larger scene keeps both in its hierarchy's leaves (pvol_bvh.hip)
+            H.triMat[i] = mi;
+            H.triFlip[i] = s->triangles[i].flip_normal;
+        }
     }
     world_sphere(s, H.worldCenter, &H.worldRadius);
     int n = (int)s->n_lights;
@@ -220,6 +224,12 @@ static void pad32(float *dst, const pvol_spectrum &s) {
     dst[30] = dst[31] = 0.f;
 }
 
+int pvol_get_accel_info(pvol_ctx *c, double *out2) {
+    if (!c || !out2) return PVOL_E_INVALID;
+    out2[0] = (double)c->hs.nBvhTris; out2[1] = c->bvhBuildMs;
+    return PVOL_OK;
+}
+
 int pvol_push_scene(pvol_ctx *c) {
     return ok(hipMemcpy(c->ds, &c->hs, sizeof(DevScene), hipMemcpyHostToDevice)) ? PVOL_OK : PVOL_E_NO_DEVICE;
 }
@@ -233,7 +243,7 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     const pvol_volume &v = s->volume;
     if (v.kind != PVOL_VOLUME_NONE && v.kind != PVOL_VOLUME_HOMOGENEOUS && v.kind != PVOL_VOLUME_GRID && v.kind != PVOL_VOLUME_RAINBOW)
         return PVOL_E_UNSUPPORTED;
-    if (s->n_lights > PVOL_MAX_LIGHTS || s->n_triangles > PVOL_MAX_TRIS) return PVOL_E_UNSUPPORTED;
+    if (s->n_lights > PVOL_MAX_LIGHTS || s->n_triangles > PVOL_BVH_MAX_TRIS) return PVOL_E_UNSUPPORTED;
     if ((s->n_lights && !s->lights) || (s->n_triangles && !s->triangles)) return PVOL_E_INVALID;
     if (v.kind == PVOL_VOLUME_GRID && (!v.density || v.nx < 1 || v.ny < 1 || v.nz < 1)) return PVOL_E_INVALID;
     for (uint32_t i = 0; i < s->n_lights; ++i) {
@@ -261,8 +271,10 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         d.cosFalloffStart = l.cos_falloff_start;
         pad32(d.intensity, l.intensity);
     }
-    h.nTris = (int)s->n_triangles;
-    for (uint32_t i = 0; i < s->n_triangles; ++i) {
+    const bool big = s->n_triangles > PVOL_MAX_TRIS;
+    h.nTris = big ? 0 : (int)s->n_triangles;
+    h.bvhNodes = 0; h.bvhTris = 0; h.nBvhTris = 0;
+    for (uint32_t i = 0; i < s->n_triangles && !big; ++i) {
         const pvol_triangle &t = s->triangles[i];
         for (int k = 0; k < 3; ++k) { h.tris[i].p1[k] = t.p[0][k]; h.tris[i].p2[k] = t.p[1][k]; h.tris[i].p3[k] = t.p[2][k]; }
     }
@@ -293,12 +305,61 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         int rc = fill_shoot_scene(c, s, hsh);
         if (rc != PVOL_OK) return rc;
     }
+    // more triangles than the embedded array: LBVH on the device
+    float4 *newNodes = 0, *newTris = 0;
+    double bvhMs = 0.0;
+    std::vector<int32_t> triMat(s->n_triangles);
+    for (uint32_t i = 0; i < s->n_triangles; ++i) triMat[i] = s->triangles[i].material;
+    if (big) {
+        const uint32_t n = s->n_triangles;
+        std::vector<float> tv((size_t)n * 9);
+        std::vector<int32_t> fl(n);
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < n; ++i) {
+            const pvol_triangle &t = s->triangles[i];
+            for (int v3i = 0; v3i < 3; ++v3i)
+                for (int k = 0; k < 3; ++k) {
+                    const float x = t.p[v3i][k];
+                    if (!(x == x) || fabsf(x) == INFINITY) return PVOL_E_INVALID;
+                    tv[(size_t)i * 9 + 3 * v3i + k] = x;
+                    lo[k] = std::min(lo[k], x); hi[k] = std::max(hi[k], x);
+                }
+            fl[i] = t.flip_normal;
+        }
+        const double diag = sqrt((double)(hi[0] - lo[0]) * (hi[0] - lo[0]) + (double)(hi[1] - lo[1]) * (hi[1] - lo[1]) +
+                                 (double)(hi[2] - lo[2]) * (hi[2] - lo[2]));
+        float *dTri = 0;
+        int32_t *dMat = 0, *dFlip = 0;
+        bool good = ok(hipMalloc(&dTri, tv.size() * 4)) && ok(hipMalloc(&dMat, (size_t)n * 4)) && ok(hipMalloc(&dFlip, (size_t)n * 4)) &&
+                    ok(hipMalloc(&newTris, (size_t)n * 3 * sizeof(float4))) && ok(hipMalloc(&newNodes, (size_t)(n - 1) * 4 * sizeof(float4))) &&
+                    ok(hipMemcpy(dTri, tv.data(), tv.size() * 4, hipMemcpyHostToDevice)) &&
+                    ok(hipMemcpy(dMat, triMat.data(), (size_t)n * 4, hipMemcpyHostToDevice)) &&
+                    ok(hipMemcpy(dFlip, fl.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+        if (good) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0, 0);
+            good = ok(pvol_build_bvh(dTri, dMat, dFlip, n, (float)(1e-5 * diag), newTris, newNodes, 0));
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, e0, e1);
+            bvhMs = ms;
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+        if (dTri) hipFree(dTri);
+        if (dMat) hipFree(dMat);
+        if (dFlip) hipFree(dFlip);
+        if (!good) { if (newTris) hipFree(newTris); if (newNodes) hipFree(newNodes); return PVOL_E_NO_MEMORY; }
+        h.bvhNodes = newNodes; h.bvhTris = newTris; h.nBvhTris = (int)n;
+    }
     float *newDensity = 0;
     float maxDensity = 1.f;
     if (v.kind == PVOL_VOLUME_GRID) {
         size_t nb = sizeof(float) * (size_t)v.nx * v.ny * v.nz;
-        if (!ok(hipMalloc(&newDensity, nb))) return PVOL_E_NO_MEMORY;
-        if (!ok(hipMemcpy(newDensity, v.density, nb, hipMemcpyHostToDevice))) { hipFree(newDensity); return PVOL_E_NO_DEVICE; }
+        auto dropBvh = [&]() { if (newTris) hipFree(newTris); if (newNodes) hipFree(newNodes); };
+        if (!ok(hipMalloc(&newDensity, nb))) { dropBvh(); return PVOL_E_NO_MEMORY; }
+        if (!ok(hipMemcpy(newDensity, v.density, nb, hipMemcpyHostToDevice))) { hipFree(newDensity); dropBvh(); return PVOL_E_NO_DEVICE; }
         float md = 0.f;
         for (size_t i = 0; i < nb / sizeof(float); ++i) md = std::max(md, v.density[i]);
         maxDensity = md;
@@ -308,12 +369,19 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     if (!ok(hipDeviceSynchronize()) || !ok(hipMemcpy(c->dsh, &hsh, sizeof(hsh), hipMemcpyHostToDevice)) ||
         !ok(hipMemcpy(c->ds, &h, sizeof(DevScene), hipMemcpyHostToDevice))) {
         if (newDensity) hipFree(newDensity);
+        if (newTris) hipFree(newTris);
+        if (newNodes) hipFree(newNodes);
         pvol_push_scene(c);   // best effort: put the device copy of the previous scene back
         hipMemcpy(c->dsh, &c->hsh, sizeof(c->hsh), hipMemcpyHostToDevice);
         return PVOL_E_NO_DEVICE;
     }
     if (c->dDensity) hipFree(c->dDensity);
     c->dDensity = newDensity;
+    if (c->dBvhNodes) hipFree(c->dBvhNodes);
+    if (c->dBvhTris) hipFree(c->dBvhTris);
+    c->dBvhNodes = newNodes; c->dBvhTris = newTris;
+    c->bvhBuildMs = bvhMs;
+    c->triMatHost.swap(triMat);
     c->maxDensity = maxDensity;
     pvol_free_caustic_map(c);   // the surface integrator belongs to the scene it was enabled on (h.surf is zero)
     c->hs = h;
@@ -438,8 +506,8 @@ int pvol_set_surface_integrator(pvol_ctx *c, const pvol_surface_params *sp, cons
     }
     if (sp->n_used < 1 || !(sp->max_dist > 0.f) || sp->max_specular_depth < 0) return PVOL_E_INVALID;
     // the matte subset: a specular BSDF would need the recursion of SpecularReflect / SpecularTransmit (core/integrator.cpp:177-262)
-    for (int i = 0; i < c->hs.nTris; ++i)
-        if (c->hsh.mats[c->hsh.triMat[i]].kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
+    for (size_t i = 0; i < c->triMatHost.size(); ++i)
+        if (c->hsh.mats[c->triMatHost[i]].kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
     uint32_t nPaths = sp->n_caustic_paths;
     std::vector<float> hp;
     const float *dP = 0, *dWo = 0, *dAlpha = 0;

@@ -18,7 +18,8 @@
 #include "../../include/pvol.h"
 
 #define PVOL_MAX_LIGHTS 8
-#define PVOL_MAX_TRIS 64
+#define PVOL_MAX_TRIS 64            // triangles in the DevScene itself (scalar loads); more go through the hierarchy
+#define PVOL_BVH_MAX_TRIS (1 << 24)  // pvol_bvh.hip
 #define PVOL_MAX_RING 8   // search radius in cells: rings of (dy,dz) rows, 8r rows per ring <= 64 lanes
 
 struct DevLight {
@@ -62,6 +63,10 @@ struct DevScene {
     DevLight lights[PVOL_MAX_LIGHTS];
     int32_t nTris;
     DevTri tris[PVOL_MAX_TRIS];
+    // more than PVOL_MAX_TRIS triangles: nTris is 0 and the scene is the device-built hierarchy (pvol_bvh_dev.h, pvol_bvh.hip)
+    const float4 *bvhNodes;   // [nBvhTris - 1][4], 0 = no hierarchy
+    const float4 *bvhTris;    // [nBvhTris][3] in Morton order: {p1, original index} {p2, material} {p3, flip_normal}
+    int32_t nBvhTris;
     // colour matching
     float cieX[32], cieY[32], cieZ[32];
     // integrator parameters

@@ -58,6 +58,8 @@ extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile,
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
                                       uint32_t *cellStart, uint32_t *subStart, hipStream_t stream);
+extern "C" hipError_t pvol_build_bvh(const float *dTri, const int32_t *dMat, const int32_t *dFlip, uint32_t n, float pad, float4 *tris,
+                                     float4 *nodes, hipStream_t stream);
 extern "C" hipError_t pvol_grid_occupancy(const uint32_t *cellStart, uint32_t ncells, double *sumSquares, hipStream_t stream);
 
 struct pvol_ctx {
@@ -66,6 +68,10 @@ struct pvol_ctx {
     DevScene hs;         // host copy
     DevScene *ds;        // device copy
     float *dDensity;
+    // triangle hierarchy of a scene with more than PVOL_MAX_TRIS triangles (pvol_bvh.hip), else 0
+    float4 *dBvhNodes = 0, *dBvhTris = 0;
+    std::vector<int32_t> triMatHost;   // material of every triangle of the scene (host copy, any size)
+    double bvhBuildMs = 0.0;
     // photon map
     uint32_t nPhotons;
     float *dRawP, *dRawWi, *dRawAlpha;  // upload order (kept for pvol_download_photons)

@@ -75,7 +75,7 @@ __device__ __forceinline__ int sp_lambda(float a, bool binLane) {   // extractLa
 
 // ------------------------------------------------------------------------------------------ scene queries
 struct Hit {
-    int tri;
+    int tri, mat;
     float t, rayEps;
     V3 p, dpdu, nn;
 };
@@ -85,21 +85,35 @@ __device__ bool scene_closest(const DevScene &S, const DevShootScene &H, V3 o, V
     float tk = INFINITY;
     bool any = false;
     int best = -1;
-    for (int base = 0; base < S.nTris; base += LANES) {   // at most PVOL_MAX_TRIS == 64: one pass
-        float t = 0.f;
-        const bool h = (base + lane < S.nTris) && tri_closest(S.tris[base + lane], o, d, mint, *maxt, &t);
-        const float tm = -wave_max(h ? -t : -INFINITY);
-        if (__ballot(h) && tm <= tk) {
-            const uint64_t m = __ballot(h && t == tm);
-            tk = tm;
-            best = base + 63 - __clzll((unsigned long long)m);
-            any = true;
+    V3 p1, p2, p3;
+    bool flip;
+    if (S.bvhNodes) {   // large scene: every lane walks the hierarchy with the same ray (pvol_bvh_dev.h)
+        const int slot = bvh_closest(S, o, d, mint, *maxt, &tk);
+        if (slot < 0) return false;
+        const float4 q1 = S.bvhTris[3 * slot], q2 = S.bvhTris[3 * slot + 1], q3 = S.bvhTris[3 * slot + 2];
+        p1 = v3(q1.x, q1.y, q1.z); p2 = v3(q2.x, q2.y, q2.z); p3 = v3(q3.x, q3.y, q3.z);
+        best = __float_as_int(q1.w);
+        hit->mat = __float_as_int(q2.w);
+        flip = __float_as_int(q3.w) != 0;
+    } else {
+        for (int base = 0; base < S.nTris; base += LANES) {   // at most PVOL_MAX_TRIS == 64: one pass
+            float t = 0.f;
+            const bool h = (base + lane < S.nTris) && tri_closest(S.tris[base + lane], o, d, mint, *maxt, &t);
+            const float tm = -wave_max(h ? -t : -INFINITY);
+            if (__ballot(h) && tm <= tk) {
+                const uint64_t m = __ballot(h && t == tm);
+                tk = tm;
+                best = base + 63 - __clzll((unsigned long long)m);
+                any = true;
+            }
         }
+        if (!any) return false;
+        const DevTri &tr = S.tris[best];
+        p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]); p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]); p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+        hit->mat = H.triMat[best];
+        flip = H.triFlip[best] != 0;
     }
-    if (!any) return false;
     *maxt = tk;
-    const DevTri &tr = S.tris[best];
-    V3 p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]), p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
     // shapes/trianglemesh.cpp:163-181 with the default uvs (0,0),(1,0),(1,1)
     float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
     V3 dp1 = p1 - p3, dp2 = p2 - p3;
@@ -112,7 +126,7 @@ __device__ bool scene_closest(const DevScene &S, const DevShootScene &H, V3 o, V
     hit->p = o + d * tk;
     hit->rayEps = 1e-3f * tk;
     hit->nn = normalize(cross(hit->dpdu, dpdv));   // core/diffgeom.cpp:46-54
-    if (H.triFlip[best]) hit->nn = hit->nn * -1.f;
+    if (flip) hit->nn = hit->nn * -1.f;
     return true;
 }
 
@@ -346,6 +360,7 @@ __device__ void frame_push(float *fs, float *fa, int sp, const Frame &F, float a
         w[20] = F.tag; w[21] = F.wo.x; w[22] = F.wo.y; w[23] = F.wo.z;
         w[24] = __int_as_float(F.nInt); w[25] = __int_as_float(F.state); w[26] = __int_as_float(F.nextChild);
         w[27] = __int_as_float((F.split ? 1 : 0) | (F.spec ? 2 : 0));
+        w[28] = __int_as_float(F.hit.mat);
     }
     if (lane < 32) fa[sp * 32 + lane] = alpha;
     __syncthreads();
@@ -354,7 +369,7 @@ __device__ void frame_pop(const float *fs, const float *fa, int sp, Frame &F, fl
     const float *w = fs + sp * SH_FRAME_WORDS;
     F.rayO = v3(w[0], w[1], w[2]); F.rayD = v3(w[3], w[4], w[5]);
     F.rayMint = w[6]; F.rayMaxt = w[7];
-    F.hit.tri = __float_as_int(w[8]); F.hit.t = w[9]; F.hit.rayEps = w[10];
+    F.hit.tri = __float_as_int(w[8]); F.hit.mat = __float_as_int(w[28]); F.hit.t = w[9]; F.hit.rayEps = w[10];
     F.hit.p = v3(w[11], w[12], w[13]); F.hit.dpdu = v3(w[14], w[15], w[16]); F.hit.nn = v3(w[17], w[18], w[19]);
     F.tag = w[20]; F.wo = v3(w[21], w[22], w[23]);
     F.nInt = __float_as_int(w[24]); F.state = __float_as_int(w[25]); F.nextChild = __float_as_int(w[26]);
@@ -435,7 +450,7 @@ __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float
     int mode = 0;   // 0 = CALL, 1 = SURFACE, 2 = CHILDREN, 3 = RETURN
     Frame F;        // the activation in SURFACE / CHILDREN mode
     float Falpha = 0.f;
-    F.hit.tri = 0; F.hit.t = 0.f; F.hit.rayEps = 0.f; F.hit.p = F.hit.dpdu = F.hit.nn = v3(0.f, 0.f, 0.f);
+    F.hit.tri = 0; F.hit.mat = 0; F.hit.t = 0.f; F.hit.rayEps = 0.f; F.hit.p = F.hit.dpdu = F.hit.nn = v3(0.f, 0.f, 0.f);
     F.rayO = F.rayD = F.wo = v3(0.f, 0.f, 0.f); F.rayMint = F.rayMaxt = F.tag = 0.f; F.nInt = F.state = F.nextChild = 0; F.split = F.spec = false;
     for (;;) {
         if (mode == 0) {
@@ -514,7 +529,7 @@ __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float
             // ---- surface code (photonshooter.cpp:131-197), F holds the activation
             const float tr = transmittance_bins(S, F.rayO, F.rayD, F.rayMint, F.rayMaxt, C.rng, C.sigTl, lane);
             Falpha *= tr;
-            const DevMaterial &m = H.mats[H.triMat[F.hit.tri]];
+            const DevMaterial &m = H.mats[F.hit.mat];
             bool hasNonSpecular = m.nBxdf > num_components(m, BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR);
             bool hasTransmission = num_components(m, BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR) > 0;
             bool dispersive = (m.kind == PVOL_MATERIAL_GLASS && m.vn > 0.f);
@@ -546,7 +561,7 @@ __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float
                             const V3 nf = dot(F.hit.nn, F.wo) < 0.f ? F.hit.nn * -1.f : F.hit.nn;
                             float *o = C.outRad + (size_t)C.nRad * 8;
                             if (lane < 8) o[lane] = lane == 0 ? F.hit.p.x : lane == 1 ? F.hit.p.y : lane == 2 ? F.hit.p.z : lane == 3 ? nf.x : lane == 4 ? nf.y :
-                                                    lane == 5 ? nf.z : lane == 6 ? __int_as_float(H.triMat[F.hit.tri]) : 0.f;
+                                                    lane == 5 ? nf.z : lane == 6 ? __int_as_float(F.hit.mat) : 0.f;
                         }
                         ++C.nRad;
                     }
@@ -574,7 +589,7 @@ __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float
                     a = Falpha;
                 }
                 float ud0 = rng_float<true>(C.rng, lane), ud1 = rng_float<true>(C.rng, lane), uc = rng_float<true>(C.rng, lane);
-                const DevMaterial &m = H.mats[H.triMat[F.hit.tri]];
+                const DevMaterial &m = H.mats[F.hit.mat];
                 V3 wi;
                 float pdf, fFac, fDiv;
                 int flags, fWhich;

@@ -13,7 +13,7 @@
 #define SRF_CAP 2048   // caustic bucket capacity (photons within maxdist + spread of a group's hit points)
 
 struct SurfHit {
-    int tri;
+    int tri, mat;
     float t;
     V3 p, nn;
 };
@@ -22,13 +22,27 @@ struct SurfHit {
 __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit *h) {
     float mt = INFINITY;
     int best = -1;
-    for (int i = 0; i < S.nTris; ++i) {
-        float t;
-        if (tri_closest(S.tris[i], o, d, mint, mt, &t)) { mt = t; best = i; }
+    V3 p1, p2, p3;
+    bool flip;
+    if (S.bvhNodes) {
+        const int slot = bvh_closest(S, o, d, mint, INFINITY, &mt);
+        if (slot < 0) return false;
+        const float4 q1 = S.bvhTris[3 * slot], q2 = S.bvhTris[3 * slot + 1], q3 = S.bvhTris[3 * slot + 2];
+        p1 = v3(q1.x, q1.y, q1.z); p2 = v3(q2.x, q2.y, q2.z); p3 = v3(q3.x, q3.y, q3.z);
+        best = __float_as_int(q1.w);
+        h->mat = __float_as_int(q2.w);
+        flip = __float_as_int(q3.w) != 0;
+    } else {
+        for (int i = 0; i < S.nTris; ++i) {
+            float t;
+            if (tri_closest(S.tris[i], o, d, mint, mt, &t)) { mt = t; best = i; }
+        }
+        if (best < 0) return false;
+        const DevTri &tr = S.tris[best];
+        p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]); p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]); p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+        h->mat = S.shootScene->triMat[best];
+        flip = S.shootScene->triFlip[best] != 0;
     }
-    if (best < 0) return false;
-    const DevTri &tr = S.tris[best];
-    const V3 p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]), p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]), p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
     const float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
     const V3 dp1 = p1 - p3, dp2 = p2 - p3;
     const float invdet = 1.f / (du1 * dv2 - dv1 * du2);
@@ -38,7 +52,7 @@ __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit 
     h->t = mt;
     h->p = o + d * mt;
     h->nn = normalize(cross(dpdu, dpdv));
-    if (S.shootScene->triFlip[best]) h->nn = h->nn * -1.f;
+    if (flip) h->nn = h->nn * -1.f;
     return true;
 }
 
@@ -81,7 +95,7 @@ __device__ __forceinline__ SurfLight surf_light(const DevScene &S, int ln, V3 p,
 
 // RandomUInt calls of PhotonIntegrator::Li for a camera ray that hit triangle h (in front of the sample's volume Li())
 __device__ uint32_t surf_count_draws(const DevScene &S, const SurfHit &h, V3 d, unsigned blackMask) {
-    const DevMaterial &m = S.shootScene->mats[S.shootScene->triMat[h.tri]];
+    const DevMaterial &m = S.shootScene->mats[h.mat];
     const bool lambert = m.kind == PVOL_MATERIAL_MATTE && m.nBxdf > 0;   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd
     const V3 wo = -d;
     uint32_t n = 0;
@@ -117,12 +131,12 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
         const pvol_ray pr = A.rays[have ? ri : 0];
         const V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
         SurfHit h;
-        h.tri = 0; h.t = 0.f; h.p = h.nn = v3(0.f, 0.f, 0.f);
+        h.tri = 0; h.mat = 0; h.t = 0.f; h.p = h.nn = v3(0.f, 0.f, 0.f);
         const bool hit = have && surf_closest(S, o, d, pr.mint, &h);   // the ray's maxt is this very t (the tile pre-pass clipped it)
         float Ls[32];
 #pragma unroll
         for (int b = 0; b < 32; ++b) Ls[b] = 0.f;
-        const DevMaterial &mat = S.shootScene->mats[S.shootScene->triMat[h.tri]];
+        const DevMaterial &mat = S.shootScene->mats[h.mat];
         const bool lambert = hit && mat.kind == PVOL_MATERIAL_MATTE && mat.nBxdf > 0;
         const V3 wo = -d;
         // ---- direct lighting: Ld = f * Li * (AbsDot(wi, n) / pdf), Li = light radiance * Transmittance of the shadow ray

@@ -111,23 +111,6 @@ __device__ __forceinline__ void tile_camera_ray(const TileArgs &T, float imageX,
 }
 
 // Scene::Intersect as SamplerRenderer::Li uses it (samplerrenderer.cpp:236-249): only the clipped maxt matters here
-__device__ __forceinline__ bool tri_closest_v(V3 p1, V3 p2, V3 p3, V3 o, V3 d, float mint, float maxt, float *tHit) {
-    V3 e1 = p2 - p1, e2 = p3 - p1;
-    V3 s1 = cross(d, e2);
-    float divisor = dot(s1, e1);
-    if (divisor == 0.f) return false;
-    float invDivisor = 1.f / divisor;
-    V3 s = o - p1;
-    float b1 = dot(s, s1) * invDivisor;
-    if (b1 < 0.f || b1 > 1.f) return false;
-    V3 s2 = cross(s, e1);
-    float b2 = dot(d, s2) * invDivisor;
-    if (b2 < 0.f || b1 + b2 > 1.f) return false;
-    float t = dot(e2, s2) * invDivisor;
-    if (t < mint || t > maxt) return false;
-    *tHit = t;
-    return true;
-}
 __device__ __forceinline__ float tile_clip(const float *ltri, int nTris, V3 o, V3 d) {
     float mt = INFINITY;
     for (int i = 0; i < nTris; ++i) {
@@ -147,13 +130,14 @@ struct CountConsts {
     float lo[3], hi[3];
     float stepSize;
     int volKind, nLights, nTris, lightKind;
+    bool bvh;
     float ldir[3], lpos[3], w2l[9], cosTotalWidth, cosFalloffStart;
 };
 __device__ __forceinline__ CountConsts count_consts(const DevScene &S) {
     CountConsts C;
     for (int i = 0; i < 16; ++i) C.w2v[i] = S.w2v[i];
     for (int i = 0; i < 3; ++i) { C.lo[i] = S.extLo[i]; C.hi[i] = S.extHi[i]; }
-    C.stepSize = S.stepSize; C.volKind = S.volKind; C.nLights = S.nLights; C.nTris = S.nTris;
+    C.stepSize = S.stepSize; C.volKind = S.volKind; C.nLights = S.nLights; C.nTris = S.nTris; C.bvh = S.bvhNodes != 0;
     const DevLight &light = S.lights[0];
     C.lightKind = light.kind;
     for (int i = 0; i < 3; ++i) { C.ldir[i] = light.dir[i]; C.lpos[i] = light.pos[i]; }
@@ -205,7 +189,9 @@ __device__ uint32_t tile_count_draws(const DevScene &S, const CountConsts &C, co
         // Scene::IntersectP over the world triangles, staged in LDS (12 floats each): every lane reads the same words
         // (broadcast), no early exit, so the loads of all triangles are in flight together
         bool occ = false;
-        if (trows) {   // distant light: direction-only terms precomputed per triangle
+        if (C.bvh) {   // more triangles than LDS rows: the device-built hierarchy (pvol_bvh_dev.h)
+            occ = bvh_occluded(S, vis.o, vis.d, vis.mint, vis.maxt);
+        } else if (trows) {   // distant light: direction-only terms precomputed per triangle
             if (!(dbg & 8u)) occ = tri_rows_occluded(trows, C.nTris, vis.o, vis.d, vis.mint, vis.maxt);
         } else {
             for (int t = 0; t < ((dbg & 8u) ? 0 : C.nTris); ++t) {
@@ -299,7 +285,8 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
                 tm = lerpf(L.time[i], T.shutterOpen, T.shutterClose);
                 su = L.scatter[i];
                 tile_camera_ray(T, imageX, imageY, &o, &d);
-                maxt = tile_clip(ltri, S.nTris, o, d);
+                if (S.bvhNodes) { float th; if (bvh_closest(S, o, d, 0.f, INFINITY, &th) >= 0) maxt = th; }
+                else maxt = tile_clip(ltri, S.nTris, o, d);
                 if (surfOn && maxt < INFINITY) {
                     SurfHit sh;
                     if (surf_closest(S, o, d, 0.f, &sh)) surfDraws = surf_count_draws(S, sh, d, blackMask);

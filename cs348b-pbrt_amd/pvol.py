@@ -60,6 +60,7 @@ def lib():
         L.pvol_march_kernel_name.argtypes = [C.c_void_p]
         L.pvol_check_errors.argtypes = [C.c_void_p]
         L.pvol_get_preprocess_seconds.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        L.pvol_get_accel_info.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.pvol_surface_photon_count.argtypes = [C.c_void_p, C.c_int, _u32p, _u32p]
         L.pvol_download_surface_photons.argtypes = [C.c_void_p, C.c_int, _f32p, _f32p, _f32p, C.c_uint32]
         L.pvol_radiance_photon_count.argtypes = [C.c_void_p, _u32p]
@@ -85,7 +86,7 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_download_photons", "pvol_li_batch", "pvol_li_batch_device", "pvol_li", "pvol_transmittance_batch",
            "pvol_get_stats", "pvol_enable_stats", "pvol_kernel_time_ms", "pvol_get_shoot_stats",
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
-           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_surface_photon_count",
+           "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_get_accel_info", "pvol_surface_photon_count",
            "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons",
            "pvol_set_surface_integrator"]
 
@@ -142,6 +143,12 @@ class PhotonVolume:
         v = (C.c_double * 2)()
         _check(lib().pvol_get_preprocess_seconds(self._h, v), "pvol_get_preprocess_seconds")
         return float(v[0]), float(v[1])
+
+    def accel_info(self):
+        """(triangles in the device-built hierarchy -- 0 when the scene is scanned linearly --, build milliseconds)."""
+        v = (C.c_double * 2)()
+        _check(lib().pvol_get_accel_info(self._h, v), "pvol_get_accel_info")
+        return int(v[0]), float(v[1])
 
     def surface_photons(self, kind):
         """(p, wo, alpha, n_paths) of the caustic (0) / direct (1) / indirect (2) store kept by the last preprocess()."""

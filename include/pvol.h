@@ -288,6 +288,13 @@ int pvol_get_shoot_stats(pvol_ctx *ctx, uint64_t *out12);
  * the kd-tree construction (photonshooter.cpp:502-503, core/kdtree.h:100-147). */
 int pvol_get_preprocess_seconds(pvol_ctx *ctx, double *out2);
 
+/* The triangle accelerator of the scene set last (replaces CreateBVHAccelerator / `new BVHAccel`, core/api.cpp:1284-1290,
+ * accelerators/bvh.cpp:301-389): scenes of up to 64 triangles are scanned linearly out of the scalar cache; larger ones
+ * (up to 2^24 triangles) get a linear BVH built on the device inside pvol_set_scene.  Closest / any hit results do not
+ * depend on which one serves them (smallest t; of several triangles at the same t the one latest in the scene's order).
+ * out[0] = triangles in the hierarchy (0: linear scan), out[1] = device build time in milliseconds. */
+int pvol_get_accel_info(pvol_ctx *ctx, double *out2);
+
 /* The surface stores of the last pvol_preprocess (params.keep_surface_photons = 1): what PhotonShooter::Preprocess hands to
  * its caustic / direct / indirect kd-trees (photonshooter.cpp:495-503), in the reference's merge order (:303-327).
  * kind: 0 caustic, 1 direct, 2 indirect.  n_paths = nCausticPaths / nDirectPaths / nIndirectPaths.  p, wo: 3 floats,

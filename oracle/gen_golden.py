@@ -180,9 +180,22 @@ def main_hg():
     make_case("vhg_k20", "volumescene_hg", 8, 8, 2, 12, photons="vhg", overrides={"n_used": 20, "max_dist": 0.3})
 
 
+def main_mesh():
+    """Row f4 (more triangles than a linear scan is for): the volumescene room with a 960-triangle matte ball in the medium.
+    The reference answers every hit through its BVHAccel; `units` holds 2 000 closest / any hit records (half of the rays aimed
+    at the mesh), `li` and `render` the integrator and whole render tasks with shadow rays and camera rays against the mesh."""
+    cap("scene", "meshroom", os.path.join(GOLD, "scene_meshroom.bin"))
+    cap("units", "meshroom", os.path.join(GOLD, "ref_units_meshroom.bin"))
+    shoot("meshroom", 4000, "mesh")
+    make_case("mesh", "meshroom", 16, 12, 4, 21, photons="mesh")
+    render_case("mesh", "meshroom", "mesh", 24, 16, 4, 6)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "hg":   # only the fixtures added in round 2
         return main_hg()
+    if len(sys.argv) > 1 and sys.argv[1] == "mesh":
+        return main_mesh()
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         return main_surface()
     os.makedirs(GOLD, exist_ok=True)

@@ -101,6 +101,7 @@ struct BuiltScene {
     int xres, yres, spp;
     std::vector<float> density;
     int nx, ny, nz;
+    float meshCenter[3] = {0.f, 0.f, 0.f}, meshRadius = 0.f;   // meshroom: where the hit-record rays are aimed half of the time (0: nowhere)
 };
 
 static Transform *keep(const Transform &t) { return new Transform(t); }
@@ -239,7 +240,7 @@ static const int kPrismIdx[24] = {0, 1, 2, 0, 2, 3, 1, 4, 5, 1, 5, 2, 0, 4, 1, 2
 
 // projectScene/volumescene_png.pbrt; `volKind` swaps the Volume statement, `gridN` > 0
 // makes the synthetic config-4 variant.
-static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN, float g = 0.f) {
+static void buildVolumeSceneNoFinish(BuiltScene &B, const char *volKind, int gridN, float g) {
     B.stepSize = .15f; B.nUsed = 50; B.maxDist = 0.5f; B.nVolumePhotons = 5000;
     B.shooterStep = 0.1f; B.maxPhotonDepth = 5; B.nCaustic = 5000; B.nIndirect = 0; B.finalGather = 1;
     B.xres = B.yres = 300; B.spp = 1; B.fov = 70.f;
@@ -257,6 +258,9 @@ static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN, floa
     addQuad(B, ctm, q1, m);
     addQuad(B, ctm, q2, m);
     addQuad(B, ctm, q3, m);
+}
+static void buildVolumeScene(BuiltScene &B, const char *volKind, int gridN, float g = 0.f) {
+    buildVolumeSceneNoFinish(B, volKind, gridN, g);
     finish(B);
 }
 
@@ -308,6 +312,32 @@ static void buildShootBench(BuiltScene &B) {
     finish(B);
 }
 
+// the volumescene room with a tessellated, bumpy matte ball in the medium (nu x nv quads -> 2 nu nv - 2 nu
+// triangles): more triangles than a linear scan is meant for, so the reference answers through its BVHAccel proper.
+static void buildMeshRoom(BuiltScene &B, int nu, int nv) {
+    buildVolumeSceneNoFinish(B, "homogeneous", 0, 0.f);
+    Transform ctm = Transform() * Translate(Vector(0, -0.5f, 3.5f));
+    int m = addMatte(B, .4f, .3f, .2f);
+    std::vector<float> P;
+    std::vector<int> idx;
+    const float R = 0.9f, cx = 0.5f, cy = 1.8f, cz = 0.5f;
+    for (int j = 0; j <= nv; ++j)
+        for (int i = 0; i < nu; ++i) {
+            const float th = M_PI * j / nv, ph = 2.f * M_PI * i / nu;
+            const float r = R * (1.f + 0.15f * sinf(5.f * th) * sinf(4.f * ph));
+            P.push_back(cx + r * sinf(th) * cosf(ph)); P.push_back(cy + r * cosf(th)); P.push_back(cz + r * sinf(th) * sinf(ph));
+        }
+    for (int j = 0; j < nv; ++j)
+        for (int i = 0; i < nu; ++i) {
+            const int a = j * nu + i, b = j * nu + (i + 1) % nu, c = (j + 1) * nu + (i + 1) % nu, d = (j + 1) * nu + i;
+            if (j > 0) { idx.push_back(a); idx.push_back(b); idx.push_back(c); }
+            if (j < nv - 1) { idx.push_back(a); idx.push_back(c); idx.push_back(d); }
+        }
+    addMesh(B, ctm, P.data(), (int)P.size() / 3, idx.data(), (int)idx.size(), m);
+    B.meshCenter[0] = cx; B.meshCenter[1] = cy - 0.5f; B.meshCenter[2] = cz + 3.5f; B.meshRadius = R * 1.2f;
+    finish(B);
+}
+
 static bool buildByName(BuiltScene &B, const std::string &name) {
     if (name == "volumescene_h") buildVolumeScene(B, "homogeneous", 0);
     else if (name == "volumescene_hg") buildVolumeScene(B, "homogeneous", 0, 0.6f);   // anisotropic phase function (row a16)
@@ -316,6 +346,8 @@ static bool buildByName(BuiltScene &B, const std::string &name) {
     else if (name == "volumescene_grid128") buildVolumeScene(B, "grid", 128);
     else if (name == "pinkfloyd") buildPinkFloyd(B);
     else if (name == "shootbench") buildShootBench(B);
+    else if (name == "meshroom") buildMeshRoom(B, 32, 16);
+    else if (name == "meshroom_big") buildMeshRoom(B, 256, 128);
     else return false;
     return true;
 }
@@ -901,9 +933,15 @@ static int cmdUnits(const std::string &name, const char *outPath) {
     std::vector<float> ri, ro_, bs;
     MemoryArena arena;
     int nr = 0;
-    for (int k = 0; k < 4000 && nr < 600; ++k) {
+    const bool aimed = B.meshRadius > 0.f;
+    const int wantRays = aimed ? 2000 : 600;
+    for (int k = 0; k < (aimed ? 40000 : 4000) && nr < wantRays; ++k) {
         Point o = wb.Lerp(rng.RandomFloat(), rng.RandomFloat(), rng.RandomFloat());
         Vector d = UniformSampleSphere(rng.RandomFloat(), rng.RandomFloat());
+        if (aimed && (k & 1)) {   // towards a random point of the mesh's bounding ball
+            Vector off = B.meshRadius * rng.RandomFloat() * UniformSampleSphere(rng.RandomFloat(), rng.RandomFloat());
+            d = Normalize(Point(B.meshCenter[0], B.meshCenter[1], B.meshCenter[2]) + off - o);
+        }
         float maxt = (k % 3 == 0) ? 4.f * rng.RandomFloat() : INFINITY;
         RayDifferential ray(o, d, 0.f, maxt, 0.f);
         Intersection isect;

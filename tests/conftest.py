@@ -53,6 +53,7 @@ LI_CASES = {
     "pf_k50": ("pinkfloyd", "pf"),
     "vhg": ("volumescene_hg", "vhg"),        # Henyey-Greenstein g = 0.6 (row a16): phase_hg in L_d and in the flux sum (wi4 reads)
     "vhg_k20": ("volumescene_hg", "vhg"),
+    "mesh": ("meshroom", "mesh"),            # 966 triangles (row f4): the reference's BVHAccel / the device-built hierarchy
 }
 TRANS_CASES = {"trans_vh": "volumescene_h", "trans_grid16": "volumescene_grid16"}
 
@@ -76,6 +77,7 @@ RENDER_CASES = {
     "vh64": ("volumescene_h", "vh"),        # 64 spp: one pixel per wave in the film kernel
     "grid16": ("volumescene_grid16", "grid16"),   # VolumeGrid: fused RESOLVE pre-pass + replay
     "pf": ("pinkfloyd", "pf"),              # spot light through a glass prism's triangles
+    "mesh": ("meshroom", "mesh"),           # camera rays and shadow rays against a 960-triangle ball (row f4)
 }
 # the same with the reference's surface integrator in place (ref_capture `render ... surface`): scene, photon map tag
 RENDER_SURF_CASES = {"vh_surf": ("volumescene_h", "vh"), "vh_surf64": ("volumescene_h", "vh")}

@@ -59,9 +59,11 @@ def _ctx(pvol, s, p, photons):
 
 
 @pytest.mark.parametrize("scene_name,n_photons,over", [("volumescene_h", 150000, {}),
-                                                       ("shootbench", 300000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2})])
+                                                       ("shootbench", 300000, {"n_used": 50, "max_dist": 0.5, "step_size": 0.2}),
+                                                       ("meshroom", 150000, {})])   # shadow rays through the device-built triangle hierarchy (row f4)
 def test_group_kernel_matches_oracle_on_a_dense_map(pvol, orc, vh_map, scene_name, n_photons, over):
-    """volumescene: distant light; shootbench: a SPOT light through a glass prism's triangles (falloff, 1/d^2, occlusion)."""
+    """volumescene: distant light; shootbench: a SPOT light through a glass prism's triangles (falloff, 1/d^2, occlusion);
+    meshroom: 966 triangles, every shadow ray of the kernel walks the LBVH."""
     if scene_name == "volumescene_h":
         s, p, photons = vh_map
         pv = _ctx(pvol, s, p, photons)

@@ -85,7 +85,8 @@ def test_sampling_routines_match_reference(orc, tables):
         assert (o4 == row[1:]).all()
 
 
-@pytest.mark.parametrize("scene_name", ["volumescene_h", "volumescene_hg", "volumescene_rainbow", "volumescene_grid16", "pinkfloyd", "shootbench"])
+@pytest.mark.parametrize("scene_name", ["volumescene_h", "volumescene_hg", "volumescene_rainbow", "volumescene_grid16", "pinkfloyd", "shootbench",
+                                        "meshroom"])
 def test_scene_units_match_reference(orc, scene_name):
     """Lights, closest/any hit, BSDF sampling and volume queries: the shooter's building blocks."""
     s = load_scene(scene_name)

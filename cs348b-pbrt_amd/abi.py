@@ -59,6 +59,12 @@ class Triangle(C.Structure):
     _fields_ = [("p", (C.c_float * 3) * 3), ("material", C.c_int32), ("flip_normal", C.c_int32)]
 
 
+class Sphere(C.Structure):
+    _fields_ = [("object_to_world", C.c_float * 16), ("world_to_object", C.c_float * 16), ("radius", C.c_float),
+                ("z_min", C.c_float), ("z_max", C.c_float), ("theta_min", C.c_float), ("theta_max", C.c_float), ("phi_max", C.c_float),
+                ("material", C.c_int32), ("flip_normal", C.c_int32)]
+
+
 class Scene(C.Structure):
     _fields_ = [
         ("volume", Volume),
@@ -68,6 +74,7 @@ class Scene(C.Structure):
         ("world_min", C.c_float * 3), ("world_max", C.c_float * 3),
         ("cie_x", Spectrum), ("cie_y", Spectrum), ("cie_z", Spectrum),
         ("xyz_scale", C.c_float),
+        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(Sphere)),
     ]
 
 
@@ -173,6 +180,19 @@ class SceneHolder:
         _spec(s.cie_y, b["cie.y"])
         _spec(s.cie_z, b["cie.z"])
         s.xyz_scale = float(b["xyz_scale"][0])
+        # Shape "sphere" (optional keys): o2w / w2o 16 floats each, f = radius, z_min, z_max, theta_min, theta_max, phi_max
+        ns = len(b["spheres.material"]) if "spheres.material" in b else 0
+        self.spheres = (Sphere * max(ns, 1))()
+        for i in range(ns):
+            P = self.spheres[i]
+            _fill(P.object_to_world, b["spheres.o2w"][16 * i:16 * i + 16])
+            _fill(P.world_to_object, b["spheres.w2o"][16 * i:16 * i + 16])
+            f = b["spheres.f"][6 * i:6 * i + 6]
+            P.radius, P.z_min, P.z_max, P.theta_min, P.theta_max, P.phi_max = [float(x) for x in f]
+            P.material = int(b["spheres.material"][i])
+            P.flip_normal = int(b["spheres.flip"][i])
+        s.n_spheres = ns
+        s.spheres = C.cast(self.spheres, C.POINTER(Sphere))
         self.scene = s
         self.blob = b
 

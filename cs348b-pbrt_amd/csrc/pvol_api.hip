@@ -245,6 +245,12 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         return PVOL_E_UNSUPPORTED;
     if (s->n_lights > PVOL_MAX_LIGHTS || s->n_triangles > PVOL_BVH_MAX_TRIS) return PVOL_E_UNSUPPORTED;
     if ((s->n_lights && !s->lights) || (s->n_triangles && !s->triangles)) return PVOL_E_INVALID;
+    if (s->n_spheres > PVOL_MAX_SPHERES) return PVOL_E_UNSUPPORTED;
+    if (s->n_spheres && !s->spheres) return PVOL_E_INVALID;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const pvol_sphere &sp = s->spheres[i];
+        if (!(sp.radius > 0.f) || sp.material < 0 || (uint32_t)sp.material >= std::max(1u, s->n_materials)) return PVOL_E_INVALID;
+    }
     if (v.kind == PVOL_VOLUME_GRID && (!v.density || v.nx < 1 || v.ny < 1 || v.nz < 1)) return PVOL_E_INVALID;
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const int k = s->lights[i].kind;
@@ -270,6 +276,16 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
         d.cosTotalWidth = l.cos_total_width;
         d.cosFalloffStart = l.cos_falloff_start;
         pad32(d.intensity, l.intensity);
+    }
+    h.nSpheres = (int)s->n_spheres;
+    memset(h.spheres, 0, sizeof(h.spheres));
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const pvol_sphere &sp = s->spheres[i];
+        DevSphere &d = h.spheres[i];
+        memcpy(d.o2w, sp.object_to_world, sizeof(d.o2w));
+        memcpy(d.w2o, sp.world_to_object, sizeof(d.w2o));
+        d.radius = sp.radius; d.zmin = sp.z_min; d.zmax = sp.z_max; d.thetaMin = sp.theta_min; d.thetaMax = sp.theta_max; d.phiMax = sp.phi_max;
+        d.mat = sp.material; d.flip = sp.flip_normal;
     }
     const bool big = s->n_triangles > PVOL_MAX_TRIS;
     h.nTris = big ? 0 : (int)s->n_triangles;
@@ -310,6 +326,7 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     double bvhMs = 0.0;
     std::vector<int32_t> triMat(s->n_triangles);
     for (uint32_t i = 0; i < s->n_triangles; ++i) triMat[i] = s->triangles[i].material;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) triMat.push_back(s->spheres[i].material);   // the surface integrator's matte check covers them
     if (big) {
         const uint32_t n = s->n_triangles;
         std::vector<float> tv((size_t)n * 9);

@@ -9,7 +9,7 @@
 //                             One 64-B fetch per visited node tests both children.
 //   bvhTris  [n][3]  float4: {p1, original index} {p2, material} {p3, flip_normal} in Morton order (int fields as bits).
 //
-// Results are those of the linear scan the small scenes use (and the oracle): the per-triangle arithmetic is the same
+// Results are those of the linear scan the small scenes use: the per-triangle arithmetic is the same
 // function, the smallest t wins and, of several triangles at the same t, the one with the highest ORIGINAL index -- the
 // serial scan rejects `t > maxt` only, so a later triangle at the same t replaces an earlier one.  A subtree is left out
 // only when its box (padded at build time) starts behind the best t so far, so the order of the traversal cannot show.

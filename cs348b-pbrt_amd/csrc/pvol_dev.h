@@ -20,6 +20,7 @@
 #define PVOL_MAX_LIGHTS 8
 #define PVOL_MAX_TRIS 64            // triangles in the DevScene itself (scalar loads); more go through the hierarchy
 #define PVOL_BVH_MAX_TRIS (1 << 24)  // pvol_bvh.hip
+#define PVOL_MAX_SPHERES 8
 #define PVOL_MAX_RING 8   // search radius in cells: rings of (dy,dz) rows, 8r rows per ring <= 64 lanes
 
 struct DevLight {
@@ -29,6 +30,12 @@ struct DevLight {
     float w2l[12];  // rows 0..2 of WorldToLight (vectors only)
     float cosTotalWidth, cosFalloffStart;
     float intensity[32];
+};
+
+struct DevSphere {   // shapes/sphere.cpp: what Sphere::Sphere stores
+    float o2w[16], w2o[16];
+    float radius, zmin, zmax, thetaMin, thetaMax, phiMax;
+    int32_t mat, flip;
 };
 
 struct DevTri {
@@ -67,6 +74,8 @@ struct DevScene {
     const float4 *bvhNodes;   // [nBvhTris - 1][4], 0 = no hierarchy
     const float4 *bvhTris;    // [nBvhTris][3] in Morton order: {p1, original index} {p2, material} {p3, flip_normal}
     int32_t nBvhTris;
+    int32_t nSpheres;         // analytic spheres, tested after the triangles (pvol_math.h sphere_hit)
+    DevSphere spheres[PVOL_MAX_SPHERES];
     // colour matching
     float cieX[32], cieY[32], cieZ[32];
     // integrator parameters

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     __syncthreads();
     const f4 *cA = reinterpret_cast<const f4 *>(L.cst), *cS = cA + 8, *cLe = cA + 16, *cAl = cA + 24, *cI = cA + 32, *cRs = cA + 40;
     const f4 *cX = cA + 48, *cY = cA + 56, *cZ = cA + 64;
-    const bool rowsOK = !REPLAY && nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS && !S.bvhNodes;
+    const bool rowsOK = !REPLAY && nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS && !S.bvhNodes && !S.nSpheres;
     if (rowsOK) tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), L.trows, lane);
     const int k = S.nUsed;
     const float wIso = 1.f / (4.f * K_PI);

@@ -605,7 +605,7 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
                 }
                 const float pdf = 1.f;
                 const bool distant = (light.kind == PVOL_LIGHT_DISTANT);
-                if (distant && cachedLn != ln && (S.nTris <= LANES && !S.bvhNodes)) {
+                if (distant && cachedLn != ln && (S.nTris <= LANES && !S.bvhNodes && !S.nSpheres)) {
                     triPre = tri_prepare(S, vis.d, lane);
                     V3 dv = xform_vector(S.w2v, vis.d);
                     cDvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
@@ -613,7 +613,7 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
                 }
                 bool lit = !spec_is_black(L) && pdf > 0.f;
                 if (lit) {
-                    if (distant && (S.nTris <= LANES && !S.bvhNodes)) lit = !wave_any(tri_test(triPre, vis.o, vis.d, vis.mint, vis.maxt));
+                    if (distant && (S.nTris <= LANES && !S.bvhNodes && !S.nSpheres)) lit = !wave_any(tri_test(triPre, vis.o, vis.d, vis.mint, vis.maxt));
                     else lit = !scene_occluded(S, vis, lane);
                 }
                 if (lit) {
@@ -626,7 +626,7 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
                         f4 Ttr;
                         if (inP) {   // analytic tau() from a point inside the extent
                             V3 dvInv = cDvInv;
-                            if (!(distant && (S.nTris <= LANES && !S.bvhNodes))) {
+                            if (!(distant && (S.nTris <= LANES && !S.bvhNodes && !S.nSpheres))) {
                                 V3 dv = xform_vector(S.w2v, vis.d);
                                 dvInv = v3(1.f / dv.x, 1.f / dv.y, 1.f / dv.z);
                             }
@@ -683,6 +683,7 @@ __device__ __forceinline__ float analytic_tau_length(const DevScene &S, V3 o, V3
     return len(a - b);
 }
 __device__ __forceinline__ bool lane_occluded(const DevScene &S, const RayD &vis) {
+    if (S.nSpheres && spheres_occluded(S, vis.o, vis.d, vis.mint, vis.maxt)) return true;
     if (S.bvhNodes) return bvh_occluded(S, vis.o, vis.d, vis.mint, vis.maxt);
     bool hit = false;
     for (int t = 0; t < S.nTris && !hit; ++t) hit = tri_hit(S.tris[t], vis);

@@ -197,8 +197,10 @@ __device__ __forceinline__ bool tri_closest(const DevTri &tr, V3 o, V3 d, float 
     return true;
 }
 #include "pvol_bvh_dev.h"
+#include "pvol_sphere_dev.h"
 // Scene::IntersectP (core/scene.h:57-61): one triangle per lane; a large scene walks its hierarchy (wave-uniform ray)
 __device__ __forceinline__ bool scene_occluded(const DevScene &S, const RayD &ray, int lane) {
+    if (S.nSpheres && spheres_occluded(S, ray.o, ray.d, ray.mint, ray.maxt)) return true;
     if (S.bvhNodes) return bvh_occluded(S, ray.o, ray.d, ray.mint, ray.maxt);
     bool hit = false;
     for (int base = 0; base < S.nTris; base += LANES) {

@@ -89,12 +89,15 @@ __device__ bool scene_closest(const DevScene &S, const DevShootScene &H, V3 o, V
     bool flip;
     if (S.bvhNodes) {   // large scene: every lane walks the hierarchy with the same ray (pvol_bvh_dev.h)
         const int slot = bvh_closest(S, o, d, mint, *maxt, &tk);
-        if (slot < 0) return false;
+        if (slot < 0 && !S.nSpheres) return false;
+        if (slot < 0) tk = INFINITY;
+        else {
         const float4 q1 = S.bvhTris[3 * slot], q2 = S.bvhTris[3 * slot + 1], q3 = S.bvhTris[3 * slot + 2];
         p1 = v3(q1.x, q1.y, q1.z); p2 = v3(q2.x, q2.y, q2.z); p3 = v3(q3.x, q3.y, q3.z);
         best = __float_as_int(q1.w);
         hit->mat = __float_as_int(q2.w);
         flip = __float_as_int(q3.w) != 0;
+        }
     } else {
         for (int base = 0; base < S.nTris; base += LANES) {   // at most PVOL_MAX_TRIS == 64: one pass
             float t = 0.f;
@@ -107,11 +110,28 @@ __device__ bool scene_closest(const DevScene &S, const DevShootScene &H, V3 o, V
                 any = true;
             }
         }
-        if (!any) return false;
-        const DevTri &tr = S.tris[best];
-        p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]); p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]); p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
-        hit->mat = H.triMat[best];
-        flip = H.triFlip[best] != 0;
+        if (!any && !S.nSpheres) return false;
+        if (any) {
+            const DevTri &tr = S.tris[best];
+            p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]); p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]); p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+            hit->mat = H.triMat[best];
+            flip = H.triFlip[best] != 0;
+        }
+    }
+    if (S.nSpheres) {   // Shape "sphere" (pvol_sphere_dev.h), tested after the triangles with the ray shortened to their hit
+        float ts = best >= 0 ? tk : *maxt;
+        V3 ph;
+        const int si = spheres_closest(S, o, d, mint, &ts, &ph);
+        if (si >= 0) {
+            *maxt = ts;
+            hit->tri = -1 - si;
+            hit->mat = S.spheres[si].mat;
+            hit->t = ts;
+            hit->rayEps = 5e-4f * ts;   // sphere.cpp:155
+            sphere_dg(S.spheres[si], ph, &hit->p, &hit->dpdu, &hit->nn);
+            return true;
+        }
+        if (best < 0) return false;
     }
     *maxt = tk;
     // shapes/trianglemesh.cpp:163-181 with the default uvs (0,0),(1,0),(1,1)

@@ -26,22 +26,38 @@ __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit 
     bool flip;
     if (S.bvhNodes) {
         const int slot = bvh_closest(S, o, d, mint, INFINITY, &mt);
-        if (slot < 0) return false;
+        if (slot < 0 && !S.nSpheres) return false;
+        if (slot >= 0) {
         const float4 q1 = S.bvhTris[3 * slot], q2 = S.bvhTris[3 * slot + 1], q3 = S.bvhTris[3 * slot + 2];
         p1 = v3(q1.x, q1.y, q1.z); p2 = v3(q2.x, q2.y, q2.z); p3 = v3(q3.x, q3.y, q3.z);
         best = __float_as_int(q1.w);
         h->mat = __float_as_int(q2.w);
         flip = __float_as_int(q3.w) != 0;
+        }
     } else {
         for (int i = 0; i < S.nTris; ++i) {
             float t;
             if (tri_closest(S.tris[i], o, d, mint, mt, &t)) { mt = t; best = i; }
         }
+        if (best < 0 && !S.nSpheres) return false;
+        if (best >= 0) {
+            const DevTri &tr = S.tris[best];
+            p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]); p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]); p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
+            h->mat = S.shootScene->triMat[best];
+            flip = S.shootScene->triFlip[best] != 0;
+        }
+    }
+    if (S.nSpheres) {   // Shape "sphere" (pvol_sphere_dev.h): tested after the triangles
+        V3 ph, dpduW;
+        const int si = spheres_closest(S, o, d, mint, &mt, &ph);
+        if (si >= 0) {
+            h->tri = -1 - si;
+            h->mat = S.spheres[si].mat;
+            h->t = mt;
+            sphere_dg(S.spheres[si], ph, &h->p, &dpduW, &h->nn);
+            return true;
+        }
         if (best < 0) return false;
-        const DevTri &tr = S.tris[best];
-        p1 = v3(tr.p1[0], tr.p1[1], tr.p1[2]); p2 = v3(tr.p2[0], tr.p2[1], tr.p2[2]); p3 = v3(tr.p3[0], tr.p3[1], tr.p3[2]);
-        h->mat = S.shootScene->triMat[best];
-        flip = S.shootScene->triFlip[best] != 0;
     }
     const float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
     const V3 dp1 = p1 - p3, dp2 = p2 - p3;

@@ -131,13 +131,14 @@ struct CountConsts {
     float stepSize;
     int volKind, nLights, nTris, lightKind;
     bool bvh;
+    int nSpheres;
     float ldir[3], lpos[3], w2l[9], cosTotalWidth, cosFalloffStart;
 };
 __device__ __forceinline__ CountConsts count_consts(const DevScene &S) {
     CountConsts C;
     for (int i = 0; i < 16; ++i) C.w2v[i] = S.w2v[i];
     for (int i = 0; i < 3; ++i) { C.lo[i] = S.extLo[i]; C.hi[i] = S.extHi[i]; }
-    C.stepSize = S.stepSize; C.volKind = S.volKind; C.nLights = S.nLights; C.nTris = S.nTris; C.bvh = S.bvhNodes != 0;
+    C.stepSize = S.stepSize; C.volKind = S.volKind; C.nLights = S.nLights; C.nTris = S.nTris; C.bvh = S.bvhNodes != 0; C.nSpheres = S.nSpheres;
     const DevLight &light = S.lights[0];
     C.lightKind = light.kind;
     for (int i = 0; i < 3; ++i) { C.ldir[i] = light.dir[i]; C.lpos[i] = light.pos[i]; }
@@ -189,7 +190,9 @@ __device__ uint32_t tile_count_draws(const DevScene &S, const CountConsts &C, co
         // Scene::IntersectP over the world triangles, staged in LDS (12 floats each): every lane reads the same words
         // (broadcast), no early exit, so the loads of all triangles are in flight together
         bool occ = false;
-        if (C.bvh) {   // more triangles than LDS rows: the device-built hierarchy (pvol_bvh_dev.h)
+        if (C.nSpheres && spheres_occluded(S, vis.o, vis.d, vis.mint, vis.maxt)) {
+            occ = true;
+        } else if (C.bvh) {   // more triangles than LDS rows: the device-built hierarchy (pvol_bvh_dev.h)
             occ = bvh_occluded(S, vis.o, vis.d, vis.mint, vis.maxt);
         } else if (trows) {   // distant light: direction-only terms precomputed per triangle
             if (!(dbg & 8u)) occ = tri_rows_occluded(trows, C.nTris, vis.o, vis.d, vis.mint, vis.maxt);
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
                 tile_camera_ray(T, imageX, imageY, &o, &d);
                 if (S.bvhNodes) { float th; if (bvh_closest(S, o, d, 0.f, INFINITY, &th) >= 0) maxt = th; }
                 else maxt = tile_clip(ltri, S.nTris, o, d);
+                if (S.nSpheres) { V3 ph; spheres_closest(S, o, d, 0.f, &maxt, &ph); }
                 if (surfOn && maxt < INFINITY) {
                     SurfHit sh;
                     if (surf_closest(S, o, d, 0.f, &sh)) surfDraws = surf_count_draws(S, sh, d, blackMask);

@@ -7,9 +7,8 @@ Covered: Film "image" (resolution), Sampler "lowdiscrepancy" (pixelsamples), Pix
 VolumeIntegrator "photonvolume" parameters (incl. what CreatePhotonShooter reads from both, core/photonshooter.cpp:529-548),
 Camera "perspective", the transform directives (Identity, Translate, Scale, Rotate, LookAt, Transform, ConcatTransform,
 TransformBegin/End, AttributeBegin/End, ReverseOrientation), WorldBegin/End, LightSource "point" / "spot" / "distant", Material
-"matte" / "glass" (with the fork's "Vn"), Shape "trianglemesh", Volume "homogeneous" / "rainbow" / "volumegrid", Include.
-Anything else raises Unsupported with the directive's name and line: nothing is skipped silently.  `Shape "sphere"` is
-the part of 8(f)-3 that is NOT here (no sphere intersection on the device yet).
+"matte" / "glass" (with the fork's "Vn"), Shape "trianglemesh" / "sphere", Volume "homogeneous" / "rainbow" / "volumegrid", Include.
+Anything else raises Unsupported with the directive's name and line: nothing is skipped silently.
 
 Arithmetic is float32 in the reference's operation order (Matrix4x4::Mul, Transform::operator(), Rotate, LookAt, the
 Gauss-Jordan Inverse of core/transform.cpp:76-135; transforms carry (m, mInv) pairs like core/transform.h so an inverse is the
@@ -394,6 +393,7 @@ class _Builder:
         self.vol = ("photonvolume", _Params())
         self.camera = None
         self.lights, self.tris, self.tri_mat, self.tri_flip, self.mats, self.mat_keys = [], [], [], [], [], []
+        self.spheres = []
         self.volume = None
         self.in_world = False
 
@@ -414,8 +414,19 @@ class _Builder:
         return len(self.mats) - 1
 
     def shape(self, name, ps, line):
+        if name == "sphere":    # CreateSphereShape + Sphere::Sphere (shapes/sphere.cpp:217-225, 41-49)
+            radius = ps.f("radius", 1.0)
+            z0, z1 = ps.f("zmin", -radius), ps.f("zmax", radius)
+            clamp = lambda v, lo, hi: F(min(max(F(v), F(lo)), F(hi)))   # noqa: E731
+            zmin, zmax = clamp(min(z0, z1), -radius, radius), clamp(max(z0, z1), -radius, radius)
+            acosf = lambda x: F(math.acos(float(F(x))))                  # noqa: E731
+            self.spheres.append({"o2w": self.ctm, "f": np.array([radius, zmin, zmax, acosf(clamp(F(zmin) / F(radius), -1, 1)),
+                                                                  acosf(clamp(F(zmax) / F(radius), -1, 1)),
+                                                                  _radians(clamp(ps.f("phimax", 360.0), 0, 360))], F),
+                                 "material": self._material_index(), "flip": int(self.reverse ^ bool(self.ctm.swaps_handedness()))})
+            return
         if name != "trianglemesh":
-            raise Unsupported('Shape "%s" (line %d): only "trianglemesh" is implemented' % (name, line))
+            raise Unsupported('Shape "%s" (line %d): only "trianglemesh" and "sphere" are implemented' % (name, line))
         idx = [int(v) for v in ps.one("indices", ("integer",), [])]
         P = np.array(ps.one("P", ("point",), []), F).reshape(-1, 3)
         if len(idx) % 3 or (idx and max(idx) >= len(P)):
@@ -613,6 +624,12 @@ def load(path):
     d["tris.p"] = np.concatenate(b.tris).astype(F) if b.tris else np.zeros(0, F)
     d["tris.material"] = np.array(b.tri_mat, np.int32)
     d["tris.flip"] = np.array(b.tri_flip, np.int32)
+    if b.spheres:   # optional keys (abi.SceneHolder): absent for scenes without spheres
+        d["spheres.o2w"] = np.concatenate([_mat16(x["o2w"].m) for x in b.spheres])
+        d["spheres.w2o"] = np.concatenate([_mat16(x["o2w"].minv) for x in b.spheres])
+        d["spheres.f"] = np.concatenate([x["f"] for x in b.spheres]).astype(F)
+        d["spheres.material"] = np.array([x["material"] for x in b.spheres], np.int32)
+        d["spheres.flip"] = np.array([x["flip"] for x in b.spheres], np.int32)
     M = b.mats
     d["mats.kind"] = np.array([m["kind"] for m in M], np.int32)
     for key in ("kd", "kr", "kt"):
@@ -624,6 +641,13 @@ def load(path):
     if b.tris:
         P = d["tris.p"].reshape(-1, 3)
         lo, hi = np.minimum(lo, P.min(0)), np.maximum(hi, P.max(0))
+    for x in b.spheres:   # Shape::WorldBound = ObjectToWorld(ObjectBound()) (core/shape.cpp:52-54, sphere.cpp:52-55)
+        r, z0, z1 = x["f"][0], x["f"][1], x["f"][2]
+        for cx in (-r, r):
+            for cy in (-r, r):
+                for cz in (z0, z1):
+                    w = x["o2w"].point((cx, cy, cz))
+                    lo, hi = np.minimum(lo, w), np.maximum(hi, w)
     if v is not None:   # Transform::operator()(BBox): the eight corners (core/transform.cpp:275-284)
         for cx in (v["p0"][0], v["p1"][0]):
             for cy in (v["p0"][1], v["p1"][1]):

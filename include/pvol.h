@@ -31,7 +31,7 @@ extern "C" {
 
 #define PVOL_NBINS 30
 #define PVOL_MT_N 624
-#define PVOL_ABI_VERSION 2
+#define PVOL_ABI_VERSION 3
 
 typedef enum pvol_status {
     PVOL_OK = 0,
@@ -103,6 +103,19 @@ typedef struct pvol_triangle {
     int32_t flip_normal;    /* ReverseOrientation ^ TransformSwapsHandedness (core/diffgeom.cpp:52-53) */
 } pvol_triangle;
 
+/* Shape "sphere" (shapes/sphere.cpp), intersected analytically in object space exactly as Sphere::Intersect / IntersectP do
+ * (:59-157, :160-216); the fields are what the Sphere constructor stores (:41-49).  At most 8 per scene. */
+typedef struct pvol_sphere {
+    float object_to_world[16];  /* ObjectToWorld.m                                            */
+    float world_to_object[16];  /* WorldToObject.m                                            */
+    float radius;
+    float z_min, z_max;         /* clamped to [-radius, radius] and ordered                   */
+    float theta_min, theta_max; /* acosf(Clamp(z/radius, -1, 1)) of z_min, z_max              */
+    float phi_max;              /* radians                                                    */
+    int32_t material;           /* index into materials[]                                     */
+    int32_t flip_normal;        /* ReverseOrientation ^ TransformSwapsHandedness              */
+} pvol_sphere;
+
 typedef struct pvol_scene {
     pvol_volume volume;
     uint32_t n_lights;
@@ -114,6 +127,8 @@ typedef struct pvol_scene {
     float world_min[3], world_max[3];  /* Scene::WorldBound(): geometry U volume (core/scene.cpp:59-60) */
     pvol_spectrum cie_x, cie_y, cie_z; /* SampledSpectrum::X/Y/Z bin averages (core/spectrum.h:370-381) */
     float xyz_scale;                   /* (700-400)/(CIE_Y_integral*30)  (core/spectrum.h:427-428)     */
+    uint32_t n_spheres;                /* ABI 3 */
+    const pvol_sphere *spheres;
 } pvol_scene;
 
 /* ---- integrator / shooter parameters (CreatePhotonVolumeIntegrator photonvolume.cpp:224-229,

@@ -32,6 +32,7 @@
 #include "shape.h"
 #include "camera.h"
 #include "shapes/trianglemesh.h"
+#include "shapes/sphere.h"
 #include "lights/distant.h"
 #include "lights/point.h"
 #include "lights/spot.h"
@@ -73,6 +74,7 @@ public:
     void Preprocess(const Scene *scene, const Camera *, const Renderer *) {
         std::vector<pvol_light> lights;
         std::vector<pvol_triangle> tris;
+        std::vector<pvol_sphere> spheres;
         std::vector<pvol_material> mats;
         std::map<const Material *, int> matIndex;
         pvol_scene s;
@@ -85,9 +87,24 @@ public:
         for (size_t i = 0; i < leaves.size(); ++i) {
             const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(leaves[i].GetPtr());
             const Triangle *tri = gp ? dynamic_cast<const Triangle *>(gp->shape.GetPtr()) : NULL;
-            if (!tri) Severe("photonvolume_hip: only triangle meshes are supported on the photon path");
+            const Sphere *sph = gp ? dynamic_cast<const Sphere *>(gp->shape.GetPtr()) : NULL;
+            if (!tri && !sph) Severe("photonvolume_hip: only triangle meshes and spheres are supported on the photon path");
             const Material *m = gp->material.GetPtr();
             if (!matIndex.count(m)) { matIndex[m] = (int)mats.size(); mats.push_back(flattenMaterial(m)); }
+            if (sph) {   // shapes/sphere.cpp:41-49: what the constructor stored
+                pvol_sphere q;
+                for (int r = 0; r < 4; ++r)
+                    for (int c = 0; c < 4; ++c) {
+                        q.object_to_world[4 * r + c] = sph->ObjectToWorld->m.m[r][c];
+                        q.world_to_object[4 * r + c] = sph->WorldToObject->m.m[r][c];
+                    }
+                q.radius = sph->radius; q.z_min = sph->zmin; q.z_max = sph->zmax;
+                q.theta_min = sph->thetaMin; q.theta_max = sph->thetaMax; q.phi_max = sph->phiMax;
+                q.material = matIndex[m];
+                q.flip_normal = (sph->ReverseOrientation ^ sph->TransformSwapsHandedness) ? 1 : 0;
+                spheres.push_back(q);
+                continue;
+            }
             pvol_triangle t;
             for (int k = 0; k < 3; ++k) {
                 const Point &p = tri->mesh->p[tri->v[k]];
@@ -100,6 +117,7 @@ public:
         s.n_lights = (uint32_t)lights.size(); s.lights = lights.empty() ? NULL : &lights[0];
         s.n_triangles = (uint32_t)tris.size(); s.triangles = tris.empty() ? NULL : &tris[0];
         s.n_materials = (uint32_t)mats.size(); s.materials = mats.empty() ? NULL : &mats[0];
+        s.n_spheres = (uint32_t)spheres.size(); s.spheres = spheres.empty() ? NULL : &spheres[0];
         const BBox &wb = scene->WorldBound();
         s.world_min[0] = wb.pMin.x; s.world_min[1] = wb.pMin.y; s.world_min[2] = wb.pMin.z;
         s.world_max[0] = wb.pMax.x; s.world_max[1] = wb.pMax.y; s.world_max[2] = wb.pMax.z;

@@ -191,11 +191,26 @@ def main_mesh():
     render_case("mesh", "meshroom", "mesh", 24, 16, 4, 6)
 
 
+def main_sphere():
+    """Row f3, Shape "sphere": the reference's sphere scene (a glass ball in the medium, spot + point light) -- `spherescene` is
+    that file as the reference's API builds it (held against the scene-file front end), `sphereroom` adds a partial matte
+    sphere under a rotation and a non-uniform scale.  Hits, BSDF samples, Li records and whole render tasks come from the
+    reference's Sphere::Intersect / IntersectP through its BVHAccel."""
+    cap("scene", "spherescene", os.path.join(GOLD, "scene_spherescene.bin"))
+    cap("scene", "sphereroom", os.path.join(GOLD, "scene_sphereroom.bin"))
+    cap("units", "sphereroom", os.path.join(GOLD, "ref_units_sphereroom.bin"))
+    shoot("sphereroom", 4000, "sph")
+    make_case("sph", "sphereroom", 14, 12, 3, 31, photons="sph", overrides={"n_used": 50, "step_size": 0.1})
+    render_case("sph", "sphereroom", "sph", 24, 16, 4, 6, stepsize=0.1, nused=50)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "hg":   # only the fixtures added in round 2
         return main_hg()
     if len(sys.argv) > 1 and sys.argv[1] == "mesh":
         return main_mesh()
+    if len(sys.argv) > 1 and sys.argv[1] == "sphere":
+        return main_sphere()
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         return main_surface()
     os.makedirs(GOLD, exist_ok=True)

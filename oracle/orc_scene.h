@@ -39,7 +39,15 @@ struct Triangle {
     int flip;
 };
 
+struct Sphere {   // shapes/sphere.cpp:41-49
+    float o2w[16], w2o[16];
+    float radius, zmin, zmax, thetaMin, thetaMax, phiMax;
+    int material;
+    int flip;
+};
+
 struct Scene {
+    std::vector<Sphere> spheres;
     Volume vol;
     std::vector<Light> lights;
     std::vector<Triangle> tris;
@@ -85,6 +93,15 @@ inline void scene_from_pod(const pvol_scene *s, Scene *out) {
         t.p3 = v3(pt.p[2][0], pt.p[2][1], pt.p[2][2]);
         t.material = pt.material;
         t.flip = pt.flip_normal;
+    }
+    out->spheres.resize(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const pvol_sphere &ps = s->spheres[i];
+        Sphere &q = out->spheres[i];
+        memcpy(q.o2w, ps.object_to_world, sizeof(q.o2w));
+        memcpy(q.w2o, ps.world_to_object, sizeof(q.w2o));
+        q.radius = ps.radius; q.zmin = ps.z_min; q.zmax = ps.z_max; q.thetaMin = ps.theta_min; q.thetaMax = ps.theta_max; q.phiMax = ps.phi_max;
+        q.material = ps.material; q.flip = ps.flip_normal;
     }
     out->mats.resize(s->n_materials);
     for (uint32_t i = 0; i < s->n_materials; ++i) {
@@ -209,6 +226,56 @@ inline bool tri_hit(const Triangle &tr, const Ray &ray, float *tHit, float *b1o,
     return true;
 }
 
+// ------------------------------------------------------------------ spheres
+// Sphere::Intersect / IntersectP (shapes/sphere.cpp:59-104, 160-216): the ray goes to object space (core/transform.h:260-269),
+// Quadratic (core/pbrt.h:309-323), nearest root inside [mint, maxt], z / phi clipping with the second root as fallback.
+inline float sphere_phi(const Sphere &sp, V3 *phit) {
+    if (phit->x == 0.f && phit->y == 0.f) phit->x = 1e-5f * sp.radius;
+    float phi = atan2f(phit->y, phit->x);
+    if (phi < 0.) phi += 2.f * kPi;
+    return phi;
+}
+inline bool sphere_clipped(const Sphere &sp, V3 phit, float phi) {
+    return (sp.zmin > -sp.radius && phit.z < sp.zmin) || (sp.zmax < sp.radius && phit.z > sp.zmax) || phi > sp.phiMax;
+}
+inline bool sphere_hit(const Sphere &sp, const Ray &r, float *tHit, V3 *phitOut) {
+    V3 o = xform_point(sp.w2o, r.o), d = xform_vector(sp.w2o, r.d);
+    float A = d.x * d.x + d.y * d.y + d.z * d.z;
+    float B = 2 * (d.x * o.x + d.y * o.y + d.z * o.z);
+    float C = o.x * o.x + o.y * o.y + o.z * o.z - sp.radius * sp.radius;
+    float discrim = B * B - 4.f * A * C;
+    if (discrim < 0.) return false;
+    float rootDiscrim = sqrtf(discrim);
+    float q;
+    if (B < 0) q = -.5f * (B - rootDiscrim);
+    else q = -.5f * (B + rootDiscrim);
+    float t0 = q / A, t1 = C / q;
+    if (t0 > t1) std::swap(t0, t1);
+    if (t0 > r.maxt || t1 < r.mint) return false;
+    float thit = t0;
+    if (t0 < r.mint) {
+        thit = t1;
+        if (thit > r.maxt) return false;
+    }
+    V3 phit = o + d * thit;
+    float phi = sphere_phi(sp, &phit);
+    if (sphere_clipped(sp, phit, phi)) {
+        if (thit == t1) return false;
+        if (t1 > r.maxt) return false;
+        thit = t1;
+        phit = o + d * thit;
+        phi = sphere_phi(sp, &phit);
+        if (sphere_clipped(sp, phit, phi)) return false;
+    }
+    *tHit = thit;
+    *phitOut = phit;
+    return true;
+}
+
+inline float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }   // Clamp, core/pbrt.h:223-227
+// material of a primitive: index >= 0 is a triangle, -1 - i the i-th sphere
+inline int prim_material(const Scene &sc, int prim) { return prim >= 0 ? sc.tris[prim].material : sc.spheres[-1 - prim].material; }
+
 struct Hit {
     int tri;
     float t, rayEpsilon;
@@ -230,7 +297,38 @@ inline bool scene_intersect(const Scene &sc, Ray *ray, Hit *hit) {
         hit->tri = (int)i;
         hit->t = t;
     }
+    // spheres after the triangles (GeometricPrimitive::Intersect shortens the ray after every hit, core/primitive.cpp:97-110)
+    int sph = -1;
+    V3 phit = v3(0.f, 0.f, 0.f);
+    for (size_t i = 0; i < sc.spheres.size(); ++i) {
+        float t;
+        V3 ph;
+        if (!sphere_hit(sc.spheres[i], *ray, &t, &ph)) continue;
+        any = true;
+        ray->maxt = t;
+        sph = (int)i;
+        phit = ph;
+        hit->tri = -1 - (int)i;
+        hit->t = t;
+    }
     if (!any) return false;
+    if (sph >= 0) {   // sphere.cpp:106-155: parametric derivatives in object space, taken to world space; diffgeom.cpp:46-54
+        const Sphere &sp = sc.spheres[sph];
+        float theta = acosf(clampf(phit.z / sp.radius, -1.f, 1.f));
+        float zradius = sqrtf(phit.x * phit.x + phit.y * phit.y);
+        float invzradius = 1.f / zradius;
+        float cosphi = phit.x * invzradius;
+        float sinphi = phit.y * invzradius;
+        V3 dpdu = v3(-sp.phiMax * phit.y, sp.phiMax * phit.x, 0);
+        V3 dpdv = (sp.thetaMax - sp.thetaMin) * v3(phit.z * cosphi, phit.z * sinphi, -sp.radius * sinf(theta));
+        hit->p = xform_point(sp.o2w, phit);
+        hit->dpdu = xform_vector(sp.o2w, dpdu);
+        hit->dpdv = xform_vector(sp.o2w, dpdv);
+        hit->rayEpsilon = 5e-4f * hit->t;
+        hit->nn = normalize(cross(hit->dpdu, hit->dpdv));
+        if (sp.flip) hit->nn = hit->nn * -1.f;
+        return true;
+    }
     const Triangle &tr = sc.tris[hit->tri];
     // trianglemesh.cpp:163-181: uvs = {(0,0),(1,0),(1,1)} (trianglemesh.h:86-100)
     float du1 = 0.f - 1.f, du2 = 1.f - 1.f, dv1 = 0.f - 1.f, dv2 = 0.f - 1.f;
@@ -250,6 +348,11 @@ inline bool scene_intersect_p(const Scene &sc, const Ray &ray) {
     for (size_t i = 0; i < sc.tris.size(); ++i) {
         float t;
         if (tri_hit(sc.tris[i], ray, &t, 0, 0)) return true;
+    }
+    for (size_t i = 0; i < sc.spheres.size(); ++i) {
+        float t;
+        V3 ph;
+        if (sphere_hit(sc.spheres[i], ray, &t, &ph)) return true;
     }
     return false;
 }

@@ -74,7 +74,7 @@ inline int num_components(const BxdfList &b, int flags) {  // reflection.h:534-5
 // (reflection.cpp:147-182).  Returns f; *flags = sampled BxDFType (0 when nothing was sampled).
 inline Spec bsdf_sample_f(const Scene &sc, int tri, V3 dpdu, V3 nn, V3 woW, V3 *wiW, float u0, float u1, float ucomp,
                           float *pdf, int *sampledType, const Spec &alpha) {
-    const Material &m = sc.mats[sc.tris[tri].material];
+    const Material &m = sc.mats[prim_material(sc, tri)];
     BxdfList bl = material_bxdfs(m);
     const int flagsAll = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR;
     int matchingComps = num_components(bl, flagsAll);
@@ -237,7 +237,7 @@ inline void follow_photon(const ShootShared &S, ShootTask &T, Ray photonRay, Hit
 
     // Handle photon/surface intersection (:131-189) -- with the possibly reassigned photonRay
     alpha *= transmittance(S.integ, photonRay, T.rng, 0);
-    const Material &mat = sc.mats[sc.tris[photonIsect.tri].material];
+    const Material &mat = sc.mats[prim_material(sc, photonIsect.tri)];
     BxdfList bl = material_bxdfs(mat);
     const int specularType = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_SPECULAR;
     const int allTransmission = BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR;

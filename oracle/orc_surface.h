@@ -43,7 +43,7 @@ inline float photon_kernel(V3 photonP, V3 p, float maxDist2) {
 inline Spec surface_li(const Integrator &I, const SurfaceIntegrator &S, const Ray &ray, const Hit &isect, Rng &rng, Counters *ctr,
                        std::vector<ClosePhoton> &lookupBuf, bool *supported) {
     const Scene &sc = *I.scene;
-    const Material &mat = sc.mats[sc.tris[isect.tri].material];
+    const Material &mat = sc.mats[prim_material(sc, isect.tri)];
     Spec L = spec_const(0.f);
     if (mat.kind != PVOL_MATERIAL_MATTE) { if (supported) *supported = false; return L; }
     const bool hasLambert = !is_black(mat.kd);   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd (matte.cpp:55-60)

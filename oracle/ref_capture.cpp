@@ -62,6 +62,7 @@
 #include "materials/glass.h"
 #include "materials/matte.h"
 #include "shapes/trianglemesh.h"
+#include "shapes/sphere.h"
 #include "volumes/homogeneous.h"
 #include "volumes/rainbow.h"
 #include "volumes/volumegrid.h"
@@ -89,6 +90,8 @@ struct BuiltScene {
     std::vector<int> lightKinds;
     std::vector<TriangleMesh *> meshes;
     std::vector<int> meshMaterial;
+    std::vector<Sphere *> spheres;
+    std::vector<int> sphereMaterial;
     struct Mat { int kind; Spectrum kd, kr, kt; float ior, vn; };
     std::vector<Mat> mats;
     std::vector<Reference<Material> > matRefs;
@@ -156,6 +159,20 @@ static void addMesh(BuiltScene &B, const Transform &ctm, const float *P, int nve
     B.meshes.push_back(mesh);
     B.meshMaterial.push_back(material);
     Reference<Shape> shape(mesh);
+    B.prims.push_back(new GeometricPrimitive(shape, B.matRefs[material], NULL));
+}
+
+static void addSphere(BuiltScene &B, const Transform &ctm, float radius, float zmin, float zmax, float phimax, int material) {
+    ParamSet ps;
+    ps.AddFloat("radius", &radius, 1);
+    ps.AddFloat("zmin", &zmin, 1);
+    ps.AddFloat("zmax", &zmax, 1);
+    ps.AddFloat("phimax", &phimax, 1);
+    Transform *o2w = keep(ctm), *w2o = keep(Inverse(ctm));
+    Sphere *sph = CreateSphereShape(o2w, w2o, false, ps);
+    B.spheres.push_back(sph);
+    B.sphereMaterial.push_back(material);
+    Reference<Shape> shape(sph);
     B.prims.push_back(new GeometricPrimitive(shape, B.matRefs[material], NULL));
 }
 
@@ -338,6 +355,41 @@ static void buildMeshRoom(BuiltScene &B, int nu, int nv) {
     finish(B);
 }
 
+// projectScene/scene.pbrt: a glass ball (Shape "sphere", index 1.5, Vn 0: no dispersion) in the medium, spot + point light,
+// three matte walls.  `extra` adds a second, partial matte sphere under a rotation and a non-uniform scale, so that zmin / zmax
+// / phimax clipping, the second root and a general ObjectToWorld are exercised too.
+static void buildSphereScene(BuiltScene &B, bool extra) {
+    B.stepSize = .05f; B.nUsed = 300; B.maxDist = 0.5f; B.nVolumePhotons = 1000000;
+    B.shooterStep = 0.1f; B.maxPhotonDepth = 5; B.nCaustic = 50000; B.nIndirect = 0; B.finalGather = 1;
+    B.xres = B.yres = 300; B.spp = 8; B.fov = 70.f;
+    Transform camCtm = Rotate(5, Vector(1, 0, 0));
+    B.camToWorld = Inverse(camCtm);
+    Transform ctm = Transform() * Translate(Vector(-1, -1, 3.5f));
+    float p0[3] = {-10, 0, -5}, p1[3] = {5, 5, 5};
+    B.volume = makeVolume(B, ctm, "homogeneous", p0, p1, .05f, .1f);
+    float sf[3] = {-3, 5, 0}, st[3] = {0, 2, 0};
+    addSpot(B, ctm, sf, st, 2500.f, 6.f);
+    float pf[3] = {0, 2, -4};
+    addPoint(B, ctm, pf, 8.f);
+    float kr[3] = {0, 0, 0}, kt[3] = {1, 1, 1};
+    int glass = addGlass(B, 1.5f, 0.f, kr, kt);
+    addSphere(B, ctm * Translate(Vector(0, 2, 0)), .6f, -.6f, .6f, 360.f, glass);
+    int matte = addMatte(B, .6f, .6f, .9f);
+    float q1[12] = {-5, 0, -5, 5, 0, -5, 5, 0, 5, -5, 0, 5};
+    float q2[12] = {-5, 0, 3, 5, 0, 3, 5, 10, 3, -5, 10, 3};
+    float q3[12] = {5, 0, 3, 5, 0, -3, 5, 10, -3, 5, 10, 3};
+    addQuad(B, ctm, q1, matte);
+    addQuad(B, ctm, q2, matte);
+    addQuad(B, ctm, q3, matte);
+    if (extra) {
+        int m2 = addMatte(B, .5f, .4f, .1f);
+        Transform t2 = ctm * Translate(Vector(2, 1, 1)) * Rotate(30, Vector(1, 1, 0)) * Scale(1.f, 0.7f, 1.2f);
+        addSphere(B, t2, .5f, -.3f, .4f, 270.f, m2);
+        B.meshCenter[0] = 0.f; B.meshCenter[1] = 0.5f; B.meshCenter[2] = 4.f; B.meshRadius = 2.f;
+    }
+    finish(B);
+}
+
 static bool buildByName(BuiltScene &B, const std::string &name) {
     if (name == "volumescene_h") buildVolumeScene(B, "homogeneous", 0);
     else if (name == "volumescene_hg") buildVolumeScene(B, "homogeneous", 0, 0.6f);   // anisotropic phase function (row a16)
@@ -347,6 +399,8 @@ static bool buildByName(BuiltScene &B, const std::string &name) {
     else if (name == "pinkfloyd") buildPinkFloyd(B);
     else if (name == "shootbench") buildShootBench(B);
     else if (name == "meshroom") buildMeshRoom(B, 32, 16);
+    else if (name == "spherescene") buildSphereScene(B, false);
+    else if (name == "sphereroom") buildSphereScene(B, true);
     else if (name == "meshroom_big") buildMeshRoom(B, 256, 128);
     else return false;
     return true;
@@ -423,6 +477,22 @@ static void flatten(const BuiltScene &B, Blob &out, bool withDensity) {
     out.putf("tris.p", tp);
     out.put("tris.material", blob::I32, tm.data(), tm.size());
     out.put("tris.flip", blob::I32, tf.data(), tf.size());
+
+    if (!B.spheres.empty()) {   // Shape "sphere": what Sphere::Sphere stored (shapes/sphere.cpp:41-49)
+        std::vector<float> so2w, sw2o, sf;
+        std::vector<int32_t> sm, sfl;
+        for (size_t k = 0; k < B.spheres.size(); ++k) {
+            const Sphere *sp = B.spheres[k];
+            putMat(so2w, sp->ObjectToWorld->m); putMat(sw2o, sp->WorldToObject->m);
+            float f[6] = {sp->radius, sp->zmin, sp->zmax, sp->thetaMin, sp->thetaMax, sp->phiMax};
+            sf.insert(sf.end(), f, f + 6);
+            sm.push_back(B.sphereMaterial[k]);
+            sfl.push_back((sp->ReverseOrientation ^ sp->TransformSwapsHandedness) ? 1 : 0);
+        }
+        out.putf("spheres.o2w", so2w); out.putf("spheres.w2o", sw2o); out.putf("spheres.f", sf);
+        out.put("spheres.material", blob::I32, sm.data(), sm.size());
+        out.put("spheres.flip", blob::I32, sfl.data(), sfl.size());
+    }
 
     std::vector<int32_t> mk;
     std::vector<float> kd, kr, kt, ior, vn;

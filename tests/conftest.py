@@ -54,6 +54,7 @@ LI_CASES = {
     "vhg": ("volumescene_hg", "vhg"),        # Henyey-Greenstein g = 0.6 (row a16): phase_hg in L_d and in the flux sum (wi4 reads)
     "vhg_k20": ("volumescene_hg", "vhg"),
     "mesh": ("meshroom", "mesh"),            # 966 triangles (row f4): the reference's BVHAccel / the device-built hierarchy
+    "sph": ("sphereroom", "sph"),            # Shape "sphere" (row f3): a glass ball and a partial matte sphere, spot + point light
 }
 TRANS_CASES = {"trans_vh": "volumescene_h", "trans_grid16": "volumescene_grid16"}
 
@@ -78,6 +79,7 @@ RENDER_CASES = {
     "grid16": ("volumescene_grid16", "grid16"),   # VolumeGrid: fused RESOLVE pre-pass + replay
     "pf": ("pinkfloyd", "pf"),              # spot light through a glass prism's triangles
     "mesh": ("meshroom", "mesh"),           # camera rays and shadow rays against a 960-triangle ball (row f4)
+    "sph": ("sphereroom", "sph"),           # camera rays clipped by spheres, two lights (FUSED pre-pass) (row f3)
 }
 # the same with the reference's surface integrator in place (ref_capture `render ... surface`): scene, photon map tag
 RENDER_SURF_CASES = {"vh_surf": ("volumescene_h", "vh"), "vh_surf64": ("volumescene_h", "vh")}

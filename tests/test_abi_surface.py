@@ -31,21 +31,21 @@ def test_library_exports_every_declared_symbol(pvol):
     for n in names:
         assert hasattr(L, n), "libpvol.so does not export %s" % n
     assert sorted(pvol.EXPORTS) == names
-    assert L.pvol_abi_version() == 2   # 2: pvol_render_debug.d_surf_xyz, pvol_set_surface_integrator
+    assert L.pvol_abi_version() == 3   # 2: pvol_render_debug.d_surf_xyz, pvol_set_surface_integrator; 3: pvol_scene.spheres, pvol_get_accel_info
 
 
 def test_struct_sizes_match_the_header(pvol, tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "pvol.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "pvol.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(pvol_ray),sizeof(pvol_stream),sizeof(pvol_params),sizeof(pvol_scene),sizeof(pvol_volume),"
                    "sizeof(pvol_light),sizeof(pvol_material),sizeof(pvol_triangle),sizeof(pvol_stats),"
-                   "sizeof(pvol_camera),sizeof(pvol_film),sizeof(pvol_sampler),sizeof(pvol_render_debug));return 0;}\n")
+                   "sizeof(pvol_camera),sizeof(pvol_film),sizeof(pvol_sampler),sizeof(pvol_render_debug),sizeof(pvol_sphere));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     mirrors = [abi.RAY_DTYPE.itemsize, abi.STREAM_DTYPE.itemsize, C.sizeof(abi.Params), C.sizeof(abi.Scene), C.sizeof(abi.Volume),
                C.sizeof(abi.Light), C.sizeof(abi.Material), C.sizeof(abi.Triangle), C.sizeof(abi.Stats),
-               C.sizeof(abi.Camera), C.sizeof(abi.Film), C.sizeof(abi.Sampler), C.sizeof(abi.RenderDebug)]
+               C.sizeof(abi.Camera), C.sizeof(abi.Film), C.sizeof(abi.Sampler), C.sizeof(abi.RenderDebug), C.sizeof(abi.Sphere)]
     assert sizes == mirrors
 
 

@@ -86,7 +86,7 @@ def test_sampling_routines_match_reference(orc, tables):
 
 
 @pytest.mark.parametrize("scene_name", ["volumescene_h", "volumescene_hg", "volumescene_rainbow", "volumescene_grid16", "pinkfloyd", "shootbench",
-                                        "meshroom"])
+                                        "meshroom", "sphereroom"])
 def test_scene_units_match_reference(orc, scene_name):
     """Lights, closest/any hit, BSDF sampling and volume queries: the shooter's building blocks."""
     s = load_scene(scene_name)

@@ -1,4 +1,4 @@
-"""Scene-file front end (cs348b-pbrt_amd/pbrt_scene.py, SURVEY 8(f)-3, trianglemesh subset) against what the reference's
+"""Scene-file front end (cs348b-pbrt_amd/pbrt_scene.py, SURVEY 8(f)-3: trianglemesh and sphere shapes) against what the reference's
 own parser + API layer built: the scene blobs of tests/golden/ were written by oracle/ref_capture.cpp through the reference's
 Create*() functions, ParamSet and Transform classes; the front end reproduces them bit for bit."""
 import importlib
@@ -30,7 +30,8 @@ def test_from_rgb_matches_reference_conversions():
         np.testing.assert_array_equal(ps.from_rgb((g, g, g)), t["rgb.spectra"].reshape(-1, 30)[i])
 
 
-@pytest.mark.parametrize("fixture,scene", [("volumescene_equiv.pbrt", "volumescene_rainbow"), ("pinkfloyd_equiv.pbrt", "pinkfloyd")])
+@pytest.mark.parametrize("fixture,scene", [("volumescene_equiv.pbrt", "volumescene_rainbow"), ("pinkfloyd_equiv.pbrt", "pinkfloyd"),
+                                            ("spherescene_equiv.pbrt", "spherescene")])   # Shape "sphere"
 def test_fixture_scenes_equal_the_scenes_the_reference_built(fixture, scene):
     d = ps.load(os.path.join(SCENES, fixture))
     _same(d, load_scene(scene))
@@ -42,7 +43,7 @@ def test_fixture_scenes_equal_the_scenes_the_reference_built(fixture, scene):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="the reference tree is not on this machine")
-@pytest.mark.parametrize("fname,scene", [("volumescene_png.pbrt", "volumescene_rainbow"), ("pinkfloyd.pbrt", "pinkfloyd")])
+@pytest.mark.parametrize("fname,scene", [("volumescene_png.pbrt", "volumescene_rainbow"), ("pinkfloyd.pbrt", "pinkfloyd"), ("scene.pbrt", "spherescene")])
 def test_reference_scene_files_equal_the_scenes_the_reference_built(fname, scene):
     _same(ps.load(os.path.join(REF_SCENES, fname)), load_scene(scene))
 
@@ -82,7 +83,7 @@ WorldEnd
 
 
 def test_what_is_not_covered_is_refused_by_name(tmp_path):
-    for text, what in [('Camera "perspective"\nWorldBegin\nShape "sphere" "float radius" [1]\nWorldEnd', 'Shape "sphere"'),
+    for text, what in [('Camera "perspective"\nWorldBegin\nShape "cylinder" "float radius" [1]\nWorldEnd', 'Shape "cylinder"'),
                        ('Camera "orthographic"', 'Camera "orthographic"'),
                        ('Camera "perspective"\nWorldBegin\nTexture "t" "color" "constant"\nWorldEnd', "directive Texture"),
                        ('Camera "perspective"\nWorldBegin\nLightSource "infinite"\nWorldEnd', 'LightSource "infinite"')]:

@@ -103,7 +103,8 @@ RAY_DTYPE = np.dtype([("o", "<f4", 3), ("mint", "<f4"), ("d", "<f4", 3), ("maxt"
                       ("time", "<f4"), ("scatter_u", "<f4"), ("rng_skip", "<u4"), ("flags", "<u4")])
 STREAM_DTYPE = np.dtype([("seed", "<u4"), ("first_ray", "<u4"), ("n_rays", "<u4"), ("reserved", "<u4"),
                          ("start_draw", "<u8"), ("end_draw", "<u8")])
-assert RAY_DTYPE.itemsize == 48 and STREAM_DTYPE.itemsize == 32
+TRI_DTYPE = np.dtype([("p", "<f4", (3, 3)), ("material", "<i4"), ("flip_normal", "<i4")])
+assert RAY_DTYPE.itemsize == 48 and STREAM_DTYPE.itemsize == 32 and TRI_DTYPE.itemsize == C.sizeof(Triangle)
 
 
 def _spec(dst, src):
@@ -152,16 +153,12 @@ class SceneHolder:
         s.n_lights = nl
         s.lights = C.cast(self.lights, C.POINTER(Light))
         nt = len(b["tris.material"])
-        self.tris = (Triangle * max(nt, 1))()
-        for i in range(nt):
-            T = self.tris[i]
-            for k in range(3):
-                for c in range(3):
-                    T.p[k][c] = float(b["tris.p"][9 * i + 3 * k + c])
-            T.material = int(b["tris.material"][i])
-            T.flip_normal = int(b["tris.flip"][i])
+        self.tris = np.zeros(max(nt, 1), TRI_DTYPE)   # a million triangles are one array copy, not nine million assignments
+        self.tris["p"][:nt] = np.asarray(b["tris.p"], np.float32).reshape(-1, 3, 3)
+        self.tris["material"][:nt] = b["tris.material"]
+        self.tris["flip_normal"][:nt] = b["tris.flip"]
         s.n_triangles = nt
-        s.triangles = C.cast(self.tris, C.POINTER(Triangle))
+        s.triangles = self.tris.ctypes.data_as(C.POINTER(Triangle))
         nm = len(b["mats.kind"])
         self.mats = (Material * max(nm, 1))()
         for i in range(nm):

@@ -53,12 +53,13 @@ def test_device_shooter_matches_oracle_shooter(pvol, orc, scene_name, n_photons,
     # same photons, same order
     np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=2e-4)          # positions (scene units ~10)
     np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=2e-5)          # unit directions
-    # flux per bin: 2e-4; a path that crossed a glass surface near the critical / grazing angle carries (1 - F) with F ~ 1, where
-    # one ulp of the cosine is 1e-3 of the factor, and every photon it deposits afterwards inherits that (sphereroom: the 8
-    # photons of one such path at 4e-4) -- at most 0.5 % of the photons may sit between 2e-4 and 2e-3
-    rel = np.abs(got[2] - ref[2]).max(axis=1) / np.maximum(np.abs(ref[2]).max(axis=1), 1e-12)
-    assert rel.max() <= 2e-3, rel.max()
-    assert (rel > 2e-4).mean() <= 0.005, (rel > 2e-4).sum()
+    # flux per bin: 2e-4 relative, plus 1e-5 of the map's typical photon flux absolute.  The absolute part is for photons that
+    # crossed a glass surface at a grazing angle: their weight carries (1 - F) with F within 1e-5 of 1, one ulp of the cosine
+    # (the device's sinf / cosf of the sampling routines are not the host libm's bit for bit) is then 1e-2 of the factor --
+    # and the factor itself makes the photon 1e-3 of its neighbours (sphereroom: 8 photons of 4 035, |diff| <= 2.1e-8 against
+    # fluxes of 4e-3 .. 1e-2)
+    typical = float(np.median(np.abs(ref[2]).max(axis=1)))
+    np.testing.assert_allclose(got[2], ref[2], rtol=2e-4, atol=1e-5 * typical)
     pv.close()
 
 

@@ -33,6 +33,9 @@
 #define GRP_PITCH (GRP_CAP + 4)   // floats per bucket component (x | y | z | photon index), padded for the 4-wide passes
 #define GRP_WIDEN 1.7f   // a lane's search radius^2 may grow to this multiple of its guess where the bucket covers it
 #define GRP_MINI 8    // photons of the k-th's bin a lane can rank
+#ifndef GRP_CORE_MIN
+#define GRP_CORE_MIN 8 // slots that are members for every served lane of a group-step are summed once for the wave when there are at least this many (GRP_CAP switches it off)
+#endif
 #define GRP_TRI_ROWS 8   // scenes with a distant light and at most this many triangles test shadow rays against precomputed rows
 #define GRP_WPE 3     // waves per SIMD the register allocation must leave room for
 #define GRP_U_BYTES 4096   // shared scratch: stage paint list | histogram | chunk ordering | mini lists (never live together)
@@ -681,6 +684,69 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             // bandwidth.  Two slots per iteration; acc = fma(row, 0 or 1, acc) is the exact addition for
                             // members and a no-op for the others, without a branch.
                             typedef const __attribute__((address_space(4))) nf4 cf4;
+                            // ---- shared part of the flux.  The 64 query points of a group-step lie within a fraction of the
+                            // k-NN radius of each other, so a good half of every lane's k photons are the SAME photons: the slots
+                            // that are members for EVERY served lane (AND of the member words) are summed once for the wave --
+                            // lane b (and b + 32 for every second slot) adds bin b of their rows, one coalesced 128-B row per
+                            // half-wave load -- and handed to the lanes by 30 readlanes; the per-lane loop below then runs over
+                            // the remaining slots only.  Addition order changes, nothing else.
+                            if (GRP_CORE_MIN < GRP_CAP) {
+                                const bool anyOk = __ballot(ok) != 0ull;
+                                int nCore = 0;
+                                uint32_t coreW[GRP_NW];
+#pragma unroll
+                                for (int wd = 0; wd < GRP_NW; ++wd) {
+                                    coreW[wd] = 0u;
+                                    if (wd * 32 >= Mb || !anyOk) continue;
+                                    coreW[wd] = (uint32_t)__builtin_amdgcn_readfirstlane((int)~wave_or(ok ? ~mem[wd] : 0u));
+                                    nCore += __builtin_popcount(coreW[wd]);
+                                }
+                                if (nCore >= GRP_CORE_MIN) {
+                                    // compact list of the core slots' photon indices (the mini-list columns are free by now)
+                                    uint32_t *clist = reinterpret_cast<uint32_t *>(L.miniD);
+                                    int basePos = 0;
+#pragma unroll
+                                    for (int r2 = 0; r2 < GRP_NW / 2; ++r2) {
+                                        if (r2 * 64 >= Mb) continue;
+                                        const unsigned long long c64 = (unsigned long long)coreW[2 * r2] | ((unsigned long long)coreW[2 * r2 + 1] << 32);
+                                        if ((c64 >> lane) & 1ull) clist[basePos + (int)lanes_below(c64, lane)] = __float_as_uint(bI[r2 * 64 + lane]);
+                                        basePos += __popcll(c64);
+                                    }
+                                    __syncthreads();
+                                    // eight rows per load: lane l reads the (l & 7)-th float4 of the row of list entry 8 q + (l >> 3)
+                                    const int sub = lane >> 3, quart = lane & 7;
+                                    nf4 cs4 = {0.f, 0.f, 0.f, 0.f};
+                                    for (int c0 = 0; c0 < nCore; c0 += 32) {   // up to 32 rows in flight per trip
+                                        nf4 v[4];
+#pragma unroll
+                                        for (int q = 0; q < 4; ++q) {
+                                            const int at = c0 + 8 * q + sub;
+                                            const bool on = at < nCore;
+                                            const uint32_t idx = clist[on ? at : 0];
+                                            const float4 w = S.alpha4[(size_t)idx * 8 + quart];
+                                            v[q] = on ? nf4{w.x, w.y, w.z, w.w} : nf4{0.f, 0.f, 0.f, 0.f};
+                                        }
+                                        cs4 += (v[0] + v[1]) + (v[2] + v[3]);
+                                    }
+                                    // sum over the eight row groups (lane bits 3, 4, 5): every lane with the same quartet holds the total
+                                    float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+#pragma unroll
+                                    for (int cc = 0; cc < 4; ++cc) {
+                                        float x = csv[cc];
+                                        x += dppf<DPP_ROW_ROR8>(x);
+                                        { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+                                        { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+                                        csv[cc] = x;
+                                    }
+                                    const float okf = ok ? 1.f : 0.f;
+#pragma unroll
+                                    for (int b = 0; b < 30; ++b)
+                                        acc[b] = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(csv[b & 3]), b >> 2)), okf, acc[b]);
+#pragma unroll
+                                    for (int wd = 0; wd < GRP_NW; ++wd) mem[wd] &= ~coreW[wd];
+                                    __syncthreads();
+                                }
+                            }
 #pragma unroll
                             for (int wd = 0; wd < GRP_NW; ++wd) {
                                 if (wd * 32 >= Mb) continue;

@@ -724,7 +724,8 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         if (stBytes > c->stateBytes) { if (c->dState) hipFree(c->dState); c->dState = 0; c->stateBytes = 0;
                                        if (!ok(hipMalloc(&c->dState, stBytes))) return PVOL_E_NO_MEMORY; c->stateBytes = stBytes; }
         a.records = c->dRecords; a.recStride = (uint32_t)stride; a.sliceM = sliceM; a.state = c->dState;
-        a.liteResolve = ((!tile || tileGridCount) && !c->noLite && !roulette_possible(c)) ? 1 : 0;
+        // with a tile pre-pass in FUSED mode (several lights) the flag selects the pre-pass's own geometry + RNG-only form
+        a.liteResolve = (!c->noLite && !roulette_possible(c)) ? 1 : 0;
     }
     if (par) hipMemsetAsync(c->dWords, 0, 3 * sizeof(uint32_t), stream);
     if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel

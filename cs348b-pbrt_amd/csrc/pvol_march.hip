@@ -1149,6 +1149,70 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
 // sampled unoccluded -- none of it depends on drawn values.  li_geo_kernel computes them ray-parallel (one wave per ray,
 // one march step per lane) into the record slots; li_resolve_lite_kernel then walks each stream's rays in order touching
 // only the MT19937 state: LDShuffleScrambled1D for lightNum, one draw per step, one per unoccluded sample (A.1).
+// Geometry of one ray's march steps, one step per lane: which lights are unoccluded at every step (bit ln; 0x80 = sigma_s is not
+// black there).  Shared by li_geo_kernel and the tile pre-pass of scenes with several lights (pvol_tile_dev.h).
+__device__ int geo_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr, RayRec rec, int lane, bool grid, bool blackS1,
+                       unsigned int lightBlackMask) {   // returns the ray's march-step count (0: nothing to do)
+    RayD ray;
+    ray.o = v3(pr.o[0], pr.o[1], pr.o[2]); ray.d = v3(pr.d[0], pr.d[1], pr.d[2]); ray.mint = pr.mint; ray.maxt = pr.maxt;
+    float t0, t1;
+    bool hit = S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
+    int nSamples = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
+    if (hit && nSamples > S.maxSteps) {   // the record plan cannot hold this ray: report, never guess
+        if (lane == 0) atomicAdd(&A.counters->nErrors, 1ull);
+        nSamples = 0;
+    }
+    if (lane == 0) { rec.hdr[0] = (uint32_t)nSamples; rec.hdr[1] = 0u; }
+    if (nSamples == 0) return 0;
+    const float step = (t1 - t0) / nSamples;
+    float tcur = t0 + pr.scatter_u * step;
+    for (int base = 0; base < nSamples; base += LANES) {
+        const int cnt = min(LANES, nSamples - base);
+        float tMine = 0.f;
+        for (int j = 0; j < cnt; ++j) {   // t0 is ACCUMULATED in the reference: replay the additions
+            if (lane == j) tMine = tcur;
+            tcur += step;
+        }
+        const bool on = lane < cnt;
+        const V3 p = ray.o + ray.d * tMine;
+        const V3 pv = xform_point(S.w2v, p);
+        const float dens = !on ? 0.f : (grid ? grid_density(S, pv) : (box_inside(S.extLo, S.extHi, pv) ? 1.f : 0.f));
+        unsigned int mask = 0u;
+        if (on && dens != 0.f && !blackS1 && S.nLights > 0) {   // sigma_s * dens is black iff dens == 0 or sigma_s is
+            mask = 0x80u;
+            for (int ln = 0; ln < S.nLights; ++ln) {
+                const DevLight &light = S.lights[ln];
+                RayD vis;
+                float fall = 1.f;
+                if (light.kind == PVOL_LIGHT_DISTANT) {
+                    vis.o = p; vis.d = v3(light.dir[0], light.dir[1], light.dir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
+                } else {
+                    V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
+                    V3 wo = normalize(lp - p);
+                    float dist = len(p - lp);
+                    vis.o = p; vis.d = vdiv(lp - p, dist); vis.mint = 0.f; vis.maxt = dist * (1.f - 0.f);
+                    if (light.kind == PVOL_LIGHT_SPOT) {
+                        V3 wl = normalize(v3(light.w2l[0] * -wo.x + light.w2l[1] * -wo.y + light.w2l[2] * -wo.z,
+                                             light.w2l[4] * -wo.x + light.w2l[5] * -wo.y + light.w2l[6] * -wo.z,
+                                             light.w2l[8] * -wo.x + light.w2l[9] * -wo.y + light.w2l[10] * -wo.z));
+                        float costheta = wl.z;
+                        if (costheta < light.cosTotalWidth) fall = 0.f;
+                        else if (costheta > light.cosFalloffStart) fall = 1.f;
+                        else {
+                            float delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
+                            fall = delta * delta * delta * delta;
+                        }
+                    }
+                }
+                const bool black = (fall == 0.f) || ((lightBlackMask >> ln) & 1u);
+                if (!black && !lane_occluded(S, vis)) mask |= 1u << ln;
+            }
+        }
+        if (on) rec.stepByte[base + lane] = (unsigned char)mask;
+    }
+    return nSamples;
+}
+
 template <int NREG>
 __global__ __launch_bounds__(LANES) void li_geo_kernel(LiArgs A) {
     const DevScene &S = *A.scene;
@@ -1173,62 +1237,65 @@ __global__ __launch_bounds__(LANES) void li_geo_kernel(LiArgs A) {
         for (uint32_t l = l0; l < l1; ++l) {
             const pvol_ray pr = A.rays[(size_t)first + begin + l];
             RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + l) * A.recStride, S.maxSteps, grid);
-            RayD ray;
-            ray.o = v3(pr.o[0], pr.o[1], pr.o[2]); ray.d = v3(pr.d[0], pr.d[1], pr.d[2]); ray.mint = pr.mint; ray.maxt = pr.maxt;
-            float t0, t1;
-            bool hit = S.volKind != PVOL_VOLUME_NONE && vol_intersect(S, ray, &t0, &t1) && (t1 - t0) != 0.f;
-            int nSamples = hit ? (int)ceilf((t1 - t0) / S.stepSize) : 0;
-            if (hit && nSamples > S.maxSteps) {   // the record plan cannot hold this ray: report, never guess
-                if (lane == 0) atomicAdd(&A.counters->nErrors, 1ull);
-                nSamples = 0;
+            geo_ray(S, A, pr, rec, lane, grid, blackS1, lightBlackMask);
+        }
+    }
+}
+
+// The RNG side of one ray's Li() when no drawn value reaches a decision beyond the light choice: LDShuffleScrambled1D for
+// lightNum, one draw per step, one per unoccluded sample (A.1), 64 steps at a time.  Reads the masks geo_ray left, leaves the
+// light of every step (and the drawn tau offsets for a VolumeGrid).  Shared by li_resolve_lite_kernel and the tile pre-pass.
+__device__ void lite_ray(const DevScene &S, RayRec rec, int n, Rng &rng, float *lightNum, int lane, bool grid, int nLights) {
+    if (n > 0) {
+        // LDShuffleScrambled1D(1, n, lightNum) + (1, n, lightComp) + 2D(1, n, lightPos): 4 + 6n draws (photonvolume.cpp:137-142)
+        if (nLights > 1) {
+            const uint32_t scramble = rng_uint<true>(rng, lane);
+            for (int i = lane; i < n; i += LANES) lightNum[i] = van_der_corput((uint32_t)i, scramble);
+            rng_skip<true>(rng, (unsigned long long)n, lane);
+            __syncthreads();
+            for (int i = 0; i < n; ++i) {   // Shuffle(samples, n, 1), montecarlo.h:174-181
+                const uint32_t other = (uint32_t)i + (rng_uint<true>(rng, lane) % (uint32_t)(n - i));
+                if (lane == 0) {
+                    const float a = lightNum[i], b = lightNum[other];
+                    lightNum[i] = b;
+                    lightNum[other] = a;
+                }
             }
-            if (lane == 0) { rec.hdr[0] = (uint32_t)nSamples; rec.hdr[1] = 0u; }
-            if (nSamples == 0) continue;
-            const float step = (t1 - t0) / nSamples;
-            float tcur = t0 + pr.scatter_u * step;
-            for (int base = 0; base < nSamples; base += LANES) {
-                const int cnt = min(LANES, nSamples - base);
-                float tMine = 0.f;
-                for (int j = 0; j < cnt; ++j) {   // t0 is ACCUMULATED in the reference: replay the additions
-                    if (lane == j) tMine = tcur;
-                    tcur += step;
-                }
-                const bool on = lane < cnt;
-                const V3 p = ray.o + ray.d * tMine;
-                const V3 pv = xform_point(S.w2v, p);
-                const float dens = !on ? 0.f : (grid ? grid_density(S, pv) : (box_inside(S.extLo, S.extHi, pv) ? 1.f : 0.f));
-                unsigned int mask = 0u;
-                if (on && dens != 0.f && !blackS1 && S.nLights > 0) {   // sigma_s * dens is black iff dens == 0 or sigma_s is
-                    mask = 0x80u;
-                    for (int ln = 0; ln < S.nLights; ++ln) {
-                        const DevLight &light = S.lights[ln];
-                        RayD vis;
-                        float fall = 1.f;
-                        if (light.kind == PVOL_LIGHT_DISTANT) {
-                            vis.o = p; vis.d = v3(light.dir[0], light.dir[1], light.dir[2]); vis.mint = 0.f; vis.maxt = INFINITY;
-                        } else {
-                            V3 lp = v3(light.pos[0], light.pos[1], light.pos[2]);
-                            V3 wo = normalize(lp - p);
-                            float dist = len(p - lp);
-                            vis.o = p; vis.d = vdiv(lp - p, dist); vis.mint = 0.f; vis.maxt = dist * (1.f - 0.f);
-                            if (light.kind == PVOL_LIGHT_SPOT) {
-                                V3 wl = normalize(v3(light.w2l[0] * -wo.x + light.w2l[1] * -wo.y + light.w2l[2] * -wo.z,
-                                                     light.w2l[4] * -wo.x + light.w2l[5] * -wo.y + light.w2l[6] * -wo.z,
-                                                     light.w2l[8] * -wo.x + light.w2l[9] * -wo.y + light.w2l[10] * -wo.z));
-                                float costheta = wl.z;
-                                if (costheta < light.cosTotalWidth) fall = 0.f;
-                                else if (costheta > light.cosFalloffStart) fall = 1.f;
-                                else {
-                                    float delta = (costheta - light.cosTotalWidth) / (light.cosFalloffStart - light.cosTotalWidth);
-                                    fall = delta * delta * delta * delta;
-                                }
-                            }
-                        }
-                        const bool black = (fall == 0.f) || ((lightBlackMask >> ln) & 1u);
-                        if (!black && !lane_occluded(S, vis)) mask |= 1u << ln;
-                    }
-                }
-                if (on) rec.stepByte[base + lane] = (unsigned char)mask;
+            __syncthreads();
+            rng_skip<true>(rng, 3ull + 4ull * (unsigned long long)n, lane);
+        } else {
+            rng_skip<true>(rng, 4ull + 6ull * (unsigned long long)n, lane);
+        }
+        // one march step per lane: step i draws uTau, then uSh if its light sample is unoccluded -- the positions are the
+        // exclusive scan of (1 + shadowed) over the steps, the values come 64 at a time out of the LDS state
+        for (int base = 0; base < n; base += LANES) {
+            const int i = base + lane;
+            const bool on = i < n;
+            const unsigned int mask = on ? rec.stepByte[i] : 0u;
+            int ln = 0;
+            if (nLights > 1 && on) ln = min((int)floorf(lightNum[i] * nLights), nLights - 1);
+            const bool lit = on && (mask & 0x80u) != 0u;
+            const bool sh = lit && ((mask >> ln) & 1u) != 0u;
+            const uint32_t need = on ? (sh ? 2u : 1u) : 0u;
+            uint32_t incl = need;
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
+            incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
+            const uint32_t off = incl - need;
+            const int total = lane_i((int)incl, LANES - 1);   // <= 128
+            const uint32_t dA = rng_bulk(rng, min(total, LANES), lane);
+            const uint32_t dB = total > LANES ? rng_bulk(rng, total - LANES, lane) : 0u;
+            const uint32_t o1 = off + 1u;
+            const uint32_t t0 = (uint32_t)__shfl((int)dA, (int)(off & 63u)), t1 = (uint32_t)__shfl((int)dB, (int)(off & 63u));
+            const uint32_t s0 = (uint32_t)__shfl((int)dA, (int)(o1 & 63u)), s1 = (uint32_t)__shfl((int)dB, (int)(o1 & 63u));
+            const float uTau = ((off < 64u ? t0 : t1) & 0xffffff) / float(1 << 24);   // core/rng.cpp:59-65
+            const float uSh = sh ? ((o1 < 64u ? s0 : s1) & 0xffffff) / float(1 << 24) : 0.f;
+            if (on) {
+                rec.stepByte[i] = (unsigned char)(lit ? (unsigned int)ln : 0u);
+                if (grid) { rec.stepU[2 * i] = uTau; rec.stepU[2 * i + 1] = uSh; }
             }
         }
     }
@@ -1269,60 +1336,7 @@ __global__ __launch_bounds__(LANES) void li_resolve_lite_kernel(LiArgs A) {
         rng_skip<true>(rng, A.rays[ri].rng_skip, lane);
         const unsigned long long d0 = rng.draws;
         RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k - begin)) * A.recStride, S.maxSteps, grid);
-        const int n = (int)rec.hdr[0];
-        if (n > 0) {
-            // LDShuffleScrambled1D(1, n, lightNum) + (1, n, lightComp) + 2D(1, n, lightPos): 4 + 6n draws (photonvolume.cpp:137-142)
-            if (nLights > 1) {
-                const uint32_t scramble = rng_uint<true>(rng, lane);
-                for (int i = lane; i < n; i += LANES) lightNum[i] = van_der_corput((uint32_t)i, scramble);
-                rng_skip<true>(rng, (unsigned long long)n, lane);
-                __syncthreads();
-                for (int i = 0; i < n; ++i) {   // Shuffle(samples, n, 1), montecarlo.h:174-181
-                    const uint32_t other = (uint32_t)i + (rng_uint<true>(rng, lane) % (uint32_t)(n - i));
-                    if (lane == 0) {
-                        const float a = lightNum[i], b = lightNum[other];
-                        lightNum[i] = b;
-                        lightNum[other] = a;
-                    }
-                }
-                __syncthreads();
-                rng_skip<true>(rng, 3ull + 4ull * (unsigned long long)n, lane);
-            } else {
-                rng_skip<true>(rng, 4ull + 6ull * (unsigned long long)n, lane);
-            }
-            // one march step per lane: step i draws uTau, then uSh if its light sample is unoccluded -- the positions are the
-            // exclusive scan of (1 + shadowed) over the steps, the values come 64 at a time out of the LDS state
-            for (int base = 0; base < n; base += LANES) {
-                const int i = base + lane;
-                const bool on = i < n;
-                const unsigned int mask = on ? rec.stepByte[i] : 0u;
-                int ln = 0;
-                if (nLights > 1 && on) ln = min((int)floorf(lightNum[i] * nLights), nLights - 1);
-                const bool lit = on && (mask & 0x80u) != 0u;
-                const bool sh = lit && ((mask >> ln) & 1u) != 0u;
-                const uint32_t need = on ? (sh ? 2u : 1u) : 0u;
-                uint32_t incl = need;
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xf, 0xf, true);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xa, 0xf, false);
-                incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xc, 0xf, false);
-                const uint32_t off = incl - need;
-                const int total = lane_i((int)incl, LANES - 1);   // <= 128
-                const uint32_t dA = rng_bulk(rng, min(total, LANES), lane);
-                const uint32_t dB = total > LANES ? rng_bulk(rng, total - LANES, lane) : 0u;
-                const uint32_t o1 = off + 1u;
-                const uint32_t t0 = (uint32_t)__shfl((int)dA, (int)(off & 63u)), t1 = (uint32_t)__shfl((int)dB, (int)(off & 63u));
-                const uint32_t s0 = (uint32_t)__shfl((int)dA, (int)(o1 & 63u)), s1 = (uint32_t)__shfl((int)dB, (int)(o1 & 63u));
-                const float uTau = ((off < 64u ? t0 : t1) & 0xffffff) / float(1 << 24);   // core/rng.cpp:59-65
-                const float uSh = sh ? ((o1 < 64u ? s0 : s1) & 0xffffff) / float(1 << 24) : 0.f;
-                if (on) {
-                    rec.stepByte[i] = (unsigned char)(lit ? (unsigned int)ln : 0u);
-                    if (grid) { rec.stepU[2 * i] = uTau; rec.stepU[2 * i + 1] = uSh; }
-                }
-            }
-        }
+        lite_ray(S, rec, (int)rec.hdr[0], rng, lightNum, lane, grid, nLights);
         if (lane == 0) rec.hdr[2] = (uint32_t)(rng.draws - d0);
         if (A.draws && lane == 0) A.draws[ri] = (uint32_t)(rng.draws - d0);
     }

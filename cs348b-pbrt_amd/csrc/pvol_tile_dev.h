@@ -318,8 +318,13 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
                     const unsigned long long r0 = rng.draws;
                     const size_t rj = (size_t)st.first_ray + k + s0 + (uint32_t)j;
                     RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k + s0 + (uint32_t)j - begin)) * A.recStride, S.maxSteps, grid);
-                    f4 Lv, Tr;
-                    march_ray<false, MODE_RESOLVE, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
+                    if (A.liteResolve) {   // no drawn value decides more than the light of a step: geometry one step per lane, then the RNG alone
+                        const int nSteps = geo_ray(S, A, pr, rec, lane, grid, blackS, blackMask);
+                        lite_ray(S, rec, nSteps, rng, M.lightNum, lane, grid, S.nLights);
+                    } else {
+                        f4 Lv, Tr;
+                        march_ray<false, MODE_RESOLVE, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);
+                    }
                     if (lane == 0) rec.hdr[2] = (uint32_t)(rng.draws - r0);
                     if (A.draws && lane == 0) A.draws[rj] = (uint32_t)(rng.draws - r0);
                 }

@@ -101,3 +101,56 @@ def test_closest_and_any_hit_equal_the_linear_scan_on_37k_triangles(pvol, orc):
     assert (gd == rd).all()
     assert rel_l2(got[:, :30], ref[:, :30], floor=1e-6 * float(np.abs(ref[:, :30]).max())).max() <= 1e-4
     pv.close()
+
+
+def _edge_scene(kind):
+    """Triangle sets that stress the build: `dup` = 120 copies of one triangle (identical Morton codes: the radix tree is over the
+    index bits alone, every hit a tie in t) among the walls; `flat` = degenerate (zero-area, collinear, repeated-vertex)
+    triangles between real ones; `just_over` = 65 triangles, the smallest scene that takes the hierarchy."""
+    s = dict(load_scene("meshroom"))
+    walls = s["tris.p"].reshape(-1, 9)[:6]
+    rng = np.random.default_rng(17)
+    if kind == "dup":
+        one = np.array([[0.0, 0.2, 4.0, 1.0, 0.2, 4.0, 0.5, 1.4, 4.2]], np.float32)
+        extra = np.repeat(one, 120, axis=0)
+    elif kind == "flat":
+        good = bumpy_ball(8, 6, (0.5, 1.3, 4.0), 0.8, 3)
+        p = rng.random((40, 3)).astype(np.float32) * 2
+        bad = np.concatenate([np.concatenate([p, p, p], 1),                                   # three equal vertices
+                              np.concatenate([p, p + 1, p + 2], 1),                            # collinear
+                              np.concatenate([p, p, p + 0.5], 1)]).astype(np.float32)          # a repeated vertex
+        extra = np.concatenate([good, bad])
+        extra = extra[rng.permutation(len(extra))]
+    else:
+        extra = bumpy_ball(8, 5, (0.5, 1.3, 4.0), 0.8, 3)[:59]
+    tris = np.concatenate([walls, extra]).astype(np.float32)
+    s["tris.p"] = tris.reshape(-1)
+    s["tris.material"] = np.concatenate([np.zeros(6, np.int32), np.ones(len(extra), np.int32)])
+    s["tris.flip"] = np.zeros(len(tris), np.int32)
+    return s, len(tris)
+
+
+@pytest.mark.parametrize("kind", ["dup", "flat", "just_over"])
+def test_hierarchy_edge_cases_equal_the_linear_scan(pvol, orc, kind):
+    from test_gpu_render import _render
+    import torch
+    s, n_tris = _edge_scene(kind)
+    assert n_tris > 64
+    p = abi.params_from_blob(s)
+    h = abi.SceneHolder(s)
+    pv = pvol.PhotonVolume(p)
+    pv.set_scene(h)
+    assert pv.accel_info()[0] == n_tris
+    pv.upload_photons(*load_photons("mesh"))
+    xres, yres, spp, n_tasks = 32, 20, 2, 4
+    tasks = np.arange(n_tasks, dtype=np.uint32)
+    cam = abi.perspective_camera(float(s["camera.fov"][0]), xres, yres, s["camera.c2w"])
+    film = abi.make_film(xres, yres, orc.gaussian_filter_table())
+    smp = abi.make_sampler(xres, yres, spp, n_tasks)
+    o = orc.Oracle(h, p)
+    o.set_photons(*load_photons("mesh"))
+    ref = orc.render_tasks(o, cam, film, smp, tasks, n_threads=4)
+    r = _render(torch, pv, cam, film, smp, tasks, len(ref["rays"]))
+    assert (r["rays"]["maxt"] == ref["rays"]["maxt"]).all()        # closest hit, bit for bit
+    assert (r["streams"]["end_draw"] == ref["end_draws"]).all()     # every shadow-ray outcome of every march step (draw counts)
+    pv.close()

@@ -138,7 +138,7 @@ def shoot(scene_name, n_photons, tag, n_tasks=1, **over):
     print("photons_%s: %d photons, %d paths" % (tag, len(P), st["paths"]))
 
 
-def shoot_caustic(scene_name, n_photons, tag, n_tasks=1, **over):
+def shoot_caustic(scene_name, n_photons, tag, n_tasks=1, keep=None, **over):
     """The caustic store of the oracle shooter's run that also made photons_<tag> (same seeds, same paths): input of the
     surface integrator's captures.  The reference's own shooter cannot be linked here (oracle/Makefile)."""
     scene = blob.load(os.path.join(GOLD, "scene_%s.bin" % scene_name))
@@ -147,6 +147,8 @@ def shoot_caustic(scene_name, n_photons, tag, n_tasks=1, **over):
     oc.keep_surface_photons(True)
     assert oc.shoot(n_tasks, 1) == 0
     P, W, A, npaths = oc.surface_photons(0)
+    if keep is not None:   # an input of both sides: the first `keep` photons are as good a caustic map as all of them, and smaller
+        P, W, A = P[:keep], W[:keep], A[:keep]
     blob.save(os.path.join(GOLD, "caustic_%s.bin" % tag), {"p": P.reshape(-1), "wo": W.reshape(-1), "alpha": A.reshape(-1),
                                                             "n_paths": np.array([npaths], np.uint32)})
     print("caustic_%s: %d photons, %d paths" % (tag, len(P), npaths))
@@ -204,6 +206,18 @@ def main_sphere():
     render_case("sph", "sphereroom", "sph", 24, 16, 4, 6, stepsize=0.1, nused=50)
 
 
+def main_specular():
+    """Row f2, the specular recursion (SpecularReflect / SpecularTransmit, core/integrator.cpp:177-262): camera rays that meet
+    the glass prism of pinkfloyd / the glass ball of the sphere scene spawn rays through SamplerRenderer::Li, whose surface and
+    volume terms draw from the same stream before the primary ray's volume term does.  Captured with the reference's own
+    PhotonIntegrator; the frames are aimed at the glass (small windows of a larger frame via `tasks`)."""
+    shoot_caustic("pinkfloyd", 6000, "pf", keep=3000)
+    render_case("pf_surf", "pinkfloyd", "pf", 48, 48, 4, 16, tasks=[1, 2, 5, 6], surface=os.path.join(GOLD, "caustic_pf.bin"))
+    shoot_caustic("sphereroom", 4000, "sph", keep=3000)
+    render_case("sph_surf", "sphereroom", "sph", 32, 32, 4, 16, tasks=[5, 6, 9, 10], stepsize=0.1, nused=50,
+                surface=os.path.join(GOLD, "caustic_sph.bin"))
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "hg":   # only the fixtures added in round 2
         return main_hg()
@@ -211,6 +225,8 @@ def main():
         return main_mesh()
     if len(sys.argv) > 1 and sys.argv[1] == "sphere":
         return main_sphere()
+    if len(sys.argv) > 1 and sys.argv[1] == "specular":
+        return main_specular()
     if len(sys.argv) > 1 and sys.argv[1] == "surface":
         return main_surface()
     os.makedirs(GOLD, exist_ok=True)

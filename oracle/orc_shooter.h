@@ -73,14 +73,20 @@ inline int num_components(const BxdfList &b, int flags) {  // reflection.h:534-5
 // `alpha` is the photon weight handed to SpecularTransmission::Sample_f for dispersion
 // (reflection.cpp:147-182).  Returns f; *flags = sampled BxDFType (0 when nothing was sampled).
 inline Spec bsdf_sample_f(const Scene &sc, int tri, V3 dpdu, V3 nn, V3 woW, V3 *wiW, float u0, float u1, float ucomp,
-                          float *pdf, int *sampledType, const Spec &alpha) {
+                          float *pdf, int *sampledType, const Spec &alpha,
+                          int flags = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR) {
     const Material &m = sc.mats[prim_material(sc, tri)];
     BxdfList bl = material_bxdfs(m);
-    const int flagsAll = BSDF_REFLECTION | BSDF_TRANSMISSION | BSDF_DIFFUSE | BSDF_GLOSSY | BSDF_SPECULAR;
+    const int flagsAll = flags;   // the shooter passes BSDF_ALL; SpecularReflect / SpecularTransmit restrict it (core/integrator.cpp:183,224)
     int matchingComps = num_components(bl, flagsAll);
     if (matchingComps == 0) { *pdf = 0.f; *sampledType = 0; return spec_const(0.f); }
     int which = std::min((int)floorf(ucomp * matchingComps), matchingComps - 1);
-    int type = bl.type[which];
+    int type = 0;
+    {   // the which-th MATCHING component (reflection.cpp:546-553)
+        int count = which;
+        for (int i = 0; i < bl.n; ++i)
+            if ((bl.type[i] & flagsAll) == bl.type[i] && count-- == 0) { type = bl.type[i]; break; }
+    }
     V3 sn = normalize(dpdu);
     V3 tn = cross(nn, sn);
     V3 wo = v3(dot(woW, sn), dot(woW, tn), dot(woW, nn));

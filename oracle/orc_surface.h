@@ -13,6 +13,7 @@
 #ifndef ORC_SURFACE_H
 #define ORC_SURFACE_H
 #include "orc_integrator.h"
+#include "orc_shooter.h"   // material_bxdfs, bsdf_sample_f: the BSDFs the photon side already restates
 
 namespace orc {
 
@@ -38,14 +39,63 @@ inline float photon_kernel(V3 photonP, V3 p, float maxDist2) {
     return 3.f * kInvPi * s * s;
 }
 
-// Returns Li of the surface integrator at a hit of `ray`; advances rng exactly as the reference does.  `supported` is cleared
-// when the hit needs what this restatement leaves out (a specular BSDF: the recursion of SpecularReflect/Transmit).
+struct SpecCtx {   // what the specular recursion carries besides the ray: the camera sample's scatter offset (every nested
+    float scatterU;             // volume Li() reads the SAME Sample, samplerrenderer.cpp:247) and the volume integrator's scratch
+    std::vector<float> *scratch;
+};
 inline Spec surface_li(const Integrator &I, const SurfaceIntegrator &S, const Ray &ray, const Hit &isect, Rng &rng, Counters *ctr,
-                       std::vector<ClosePhoton> &lookupBuf, bool *supported) {
+                       std::vector<ClosePhoton> &lookupBuf, bool *supported, int depth = 0, const SpecCtx *sx = 0);
+
+// SamplerRenderer::Li for a spawned ray (renderers/samplerrenderer.cpp:228-251): closest hit, surface integrator, then the
+// volume integrator on the (clipped) ray; delta lights add no Le for rays that leave the scene.
+inline Spec renderer_li(const Integrator &I, const SurfaceIntegrator &S, Ray ray, int depth, Rng &rng, Counters *ctr,
+                        std::vector<ClosePhoton> &lookupBuf, bool *supported, const SpecCtx &sx) {
+    Hit hit;
+    Spec L = spec_const(0.f);
+    if (scene_intersect(*I.scene, &ray, &hit)) L = surface_li(I, S, ray, hit, rng, ctr, lookupBuf, supported, depth, &sx);
+    Spec T;
+    Spec Lvi = li(I, ray, sx.scatterU, rng, &T, ctr, *sx.scratch, lookupBuf);
+    return T * L + Lvi;
+}
+
+// SpecularReflect / SpecularTransmit (core/integrator.cpp:177-262) without the ray differentials (nothing on this path reads
+// them): BSDFSample(rng) draws three numbers, Sample_f is restricted to the one specular lobe, the spawned ray starts at
+// rayEpsilon and carries depth + 1.
+inline Spec specular_bounce(const Integrator &I, const SurfaceIntegrator &S, const Ray &ray, const Hit &isect, int lobe, int depth, Rng &rng,
+                            Counters *ctr, std::vector<ClosePhoton> &lookupBuf, bool *supported, const SpecCtx &sx) {
+    const float u0 = rng.random_float(), u1 = rng.random_float(), uc = rng.random_float();   // BSDFSample(RNG&), reflection.h:491-495
+    const V3 wo = -ray.d;
+    V3 wi = v3(0.f, 0.f, 0.f);
+    float pdf = 0.f;
+    int type = 0;
+    Spec f = bsdf_sample_f(*I.scene, isect.tri, isect.dpdu, isect.nn, wo, &wi, u0, u1, uc, &pdf, &type, spec_const(1.f), lobe | BSDF_SPECULAR);
+    Spec L = spec_const(0.f);
+    if (pdf > 0.f && !is_black(f) && fabsf(dot(wi, isect.nn)) != 0.f) {
+        Ray rd = make_ray(isect.p, wi, isect.rayEpsilon, kInfinity, ray.time);
+        Spec Li = renderer_li(I, S, rd, depth + 1, rng, ctr, lookupBuf, supported, sx);
+        L = f * Li * (fabsf(dot(wi, isect.nn)) / pdf);
+    }
+    return L;
+}
+
+// Returns Li of the surface integrator at a hit of `ray`; advances rng exactly as the reference does.  Specular surfaces recurse
+// when `sx` is given (the tile driver passes it); without it `supported` is cleared for them as before.
+inline Spec surface_li(const Integrator &I, const SurfaceIntegrator &S, const Ray &ray, const Hit &isect, Rng &rng, Counters *ctr,
+                       std::vector<ClosePhoton> &lookupBuf, bool *supported, int depth, const SpecCtx *sx) {
     const Scene &sc = *I.scene;
     const Material &mat = sc.mats[prim_material(sc, isect.tri)];
     Spec L = spec_const(0.f);
-    if (mat.kind != PVOL_MATERIAL_MATTE) { if (supported) *supported = false; return L; }
+    if (mat.kind != PVOL_MATERIAL_MATTE) {
+        if (!sx) { if (supported) *supported = false; return L; }
+        // glass (materials/glass.cpp:42-59): purely specular.  UniformSampleAllLights finds f == 0 for every light sample (no
+        // draw: the transmittance of the shadow ray is only asked for when f is not black, core/integrator.cpp:131-134);
+        // LPhoton returns before its rho() draws (no non-specular component, photonmap.cpp:66-68).
+        if (depth + 1 < S.maxSpecularDepth) {
+            L = L + specular_bounce(I, S, ray, isect, BSDF_REFLECTION, depth, rng, ctr, lookupBuf, supported, *sx);
+            L = L + specular_bounce(I, S, ray, isect, BSDF_TRANSMISSION, depth, rng, ctr, lookupBuf, supported, *sx);
+        }
+        return L;
+    }
     const bool hasLambert = !is_black(mat.kd);   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd (matte.cpp:55-60)
     const V3 wo = -ray.d;
     const V3 p = isect.p, n = isect.nn;          // dgShading == dg for a triangle without normals
@@ -85,7 +135,7 @@ inline Spec surface_li(const Integrator &I, const SurfaceIntegrator &S, const Ra
     }
     // indirect: finalGather && indirectMap != NULL is false without an indirect map; LPhoton(NULL map) adds nothing, draws nothing
     // ---- SpecularReflect + SpecularTransmit: BSDFSample(rng) is constructed before Sample_f finds no specular component
-    if (0 + 1 < S.maxSpecularDepth) rng.skip(6);
+    if (depth + 1 < S.maxSpecularDepth) rng.skip(6);
     return L;
 }
 

@@ -183,7 +183,8 @@ inline uint64_t render_task(const Integrator &I, const pvol_camera &cam, const p
                 const bool hitSurface = scene_intersect(*I.scene, &ray, &hit);   // SamplerRenderer::Li, samplerrenderer.cpp:236-249: clips ray.maxt
                 Spec Lsurf = spec_const(0.f);
                 const uint64_t ds0 = rng.draws;
-                if (SI && hitSurface) Lsurf = surface_li(I, *SI, ray, hit, rng, ctr, lookupBuf, supported);
+                SpecCtx sx = {ps.scatter[i], &scratch};
+                if (SI && hitSurface) Lsurf = surface_li(I, *SI, ray, hit, rng, ctr, lookupBuf, supported, 0, &sx);
                 const uint64_t surfDraws = rng.draws - ds0;
                 Spec T;
                 Spec Lv = li(I, ray, ps.scatter[i], rng, &T, ctr, scratch, lookupBuf);

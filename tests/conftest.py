@@ -83,12 +83,14 @@ RENDER_CASES = {
 }
 # the same with the reference's surface integrator in place (ref_capture `render ... surface`): scene, photon map tag
 RENDER_SURF_CASES = {"vh_surf": ("volumescene_h", "vh"), "vh_surf64": ("volumescene_h", "vh")}
+# ... and with specular surfaces in view: the recursion of SpecularReflect / SpecularTransmit (oracle only so far; the device refuses)
+RENDER_SPECULAR_CASES = {"pf_surf": ("pinkfloyd", "pf"), "sph_surf": ("sphereroom", "sph")}
 
 
 def load_render_case(name):
     """Returns (scene blob, params, camera, film, sampler, case blob) for a golden render case."""
     c = blob.load(os.path.join(GOLD, "render_%s.bin" % name))
-    s = load_scene((RENDER_CASES[name] if name in RENDER_CASES else RENDER_SURF_CASES[name])[0])
+    s = load_scene((RENDER_CASES[name] if name in RENDER_CASES else RENDER_SURF_CASES[name] if name in RENDER_SURF_CASES else RENDER_SPECULAR_CASES[name])[0])
     p = abi.params_from_blob(s, step_size=float(c["params.f"][0]), max_dist=float(c["params.f"][1]),
                              n_used=int(c["params.nused"][0]))
     si = c["sampler.i"]

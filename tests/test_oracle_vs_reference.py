@@ -341,6 +341,31 @@ def test_render_with_the_surface_integrator_matches_reference(orc, name):
     assert (c["surf.xyz"].reshape(-1, 3).sum(1) > 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("name,photons", [("pf_surf", "pf"), ("sph_surf", "sph")])
+def test_specular_recursion_matches_reference(orc, name, photons):
+    """SURVEY 8(f)-2, the specular part: camera samples that meet the glass prism / the glass ball go through
+    SpecularReflect + SpecularTransmit (core/integrator.cpp:177-262) -- 3 + 3 draws, a spawned ray through SamplerRenderer::Li
+    with its own surface term and its own volume Li() (same Sample, so the same scatter offset), up to maxspeculardepth levels,
+    all drawn from the tile's stream BEFORE the primary ray's volume term.  The oracle reproduces the reference's per-sample
+    surface radiance, composed radiance, draw counts, stream ends and film bit for bit."""
+    s, p, cam, film, smp, c = load_render_case(name)
+    cb = blob.load(os.path.join(GOLD, "caustic_%s.bin" % photons))
+    o = orc.Oracle(abi.SceneHolder(s), p)
+    o.set_photons(*load_photons(photons))
+    o.set_surface_integrator(int(c["surf.params.i"][0]), float(c["surf.params.f"][0]), bool(c["surf.params.i"][1]),
+                             (cb["p"].reshape(-1, 3), cb["wo"].reshape(-1, 3), cb["alpha"].reshape(-1, 30)), int(cb["n_paths"][0]))
+    r = orc.render_tasks(o, cam, film, smp, c["tasks"])
+    assert not r["unsupported_hits"]
+    np.testing.assert_array_equal(r["rays"]["rng_skip"], c["rays.skip"])
+    np.testing.assert_array_equal(r["end_draws"], c["task.end_draw"])
+    np.testing.assert_array_equal(r["surf_xyz"].ravel(), c["surf.xyz"])
+    np.testing.assert_array_equal(r["xyzT"].ravel(), c["xyzT"])
+    np.testing.assert_array_equal(r["pixels"].ravel(), c["film.pixels"])
+    # the frame is aimed at the glass: a good number of samples carry more surface draws than any matte hit makes (151): the
+    # nested volume Li() calls of the spawned rays are counted among them
+    assert (c["surf.draws"] > 151).sum() > 20, int((c["surf.draws"] > 151).sum())
+
+
 def test_ld_pixel_sample_and_filter_table_match_reference(orc):
     s, p, cam, film, smp, c = load_render_case("vh")
     np.testing.assert_array_equal(orc.gaussian_filter_table(2.0, 2.0, 2.0), c["film.filter_table"])

@@ -275,7 +275,10 @@ int pvol_create(const pvol_params *params, pvol_ctx **out);
 void pvol_destroy(pvol_ctx *ctx);
 
 /* Copies the flattened scene to the device (what Li()/followPhoton read through
- * `const Scene *`: core/scene.h:42-73).  May be called again to replace the scene. */
+ * `const Scene *`: core/scene.h:42-73) and, beyond 64 triangles, builds the triangle hierarchy there (pvol_get_accel_info).
+ * May be called again to replace the scene; a rejected scene leaves the previous one in place.
+ * Limits (PVOL_E_UNSUPPORTED): 8 lights, 2^24 triangles, 8 spheres, 8 materials; PVOL_E_INVALID: a material index out of
+ * range, a non-finite vertex, a sphere radius <= 0. */
 int pvol_set_scene(pvol_ctx *ctx, const pvol_scene *scene);
 
 /* Installs a volume photon map computed elsewhere (e.g. by the reference's own

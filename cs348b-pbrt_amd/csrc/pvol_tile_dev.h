@@ -147,9 +147,6 @@ __device__ __forceinline__ CountConsts count_consts(const DevScene &S) {
     return C;
 }
 
-#ifndef TILE_COUNT_UNROLL
-#define TILE_COUNT_UNROLL 2   // 4 measured slower than none (registers); 2: 1 989 -> 1 949 ms per C2 step
-#endif
 // Number of RandomUInt calls of one Li() when no roulette can fire and at most one light exists: 4 + 6n + n + u
 // (photonvolume.cpp:112-222; same per-step tests as march_ray_blocked's scalar phase).  One ray per lane.
 __device__ uint32_t tile_count_draws(const DevScene &S, const CountConsts &C, const float *ltri, const float *trows, V3 o, V3 d, float maxt, float scatterU, bool blackS, bool lightBlack, uint32_t dbg = 0u) {
@@ -163,35 +160,32 @@ __device__ uint32_t tile_count_draws(const DevScene &S, const CountConsts &C, co
     const bool tryLight = !blackS && C.nLights > 0 && !lightBlack;
     if (!tryLight || (dbg & 16u)) return 4u + 7u * (uint32_t)nSamples;
     if (trows && !C.bvh && !C.nSpheres && !(dbg & 8u)) {
-        // A distant light over the precomputed triangle rows: TILE_COUNT_UNROLL march steps per trip -- every row is read from LDS once for
+        // A distant light over the precomputed triangle rows: two march steps per trip (written out: the same loop over
+        // small arrays compiled to slower code, and four steps per trip measured slower than one -- registers) -- every row is read from LDS once for
         // both (the shadow rays share their direction), and the two steps' arithmetic overlaps the reads' latency.  tcur takes
         // the same additions in the same order; the count is an integer sum.
         const V3 ld = v3(C.ldir[0], C.ldir[1], C.ldir[2]);
-        for (int j = 0; j < nSamples; j += TILE_COUNT_UNROLL) {
-            V3 pp[TILE_COUNT_UNROLL];
-            bool in[TILE_COUNT_UNROLL], occ[TILE_COUNT_UNROLL];
-            bool any = false;
-#pragma unroll
-            for (int q = 0; q < TILE_COUNT_UNROLL; ++q) {
-                pp[q] = o + d * tcur;
-                tcur += step;
-                const V3 pv = xform_point(C.w2v, pp[q]);
-                in[q] = j + q < nSamples && (C.volKind == PVOL_VOLUME_GRID ? grid_density(S, pv) != 0.f : box_inside(C.lo, C.hi, pv));
-                occ[q] = false;
-                any = any || in[q];
-            }
-            if (!any) continue;
+        for (int j = 0; j < nSamples; j += 2) {
+            const V3 pA = o + d * tcur;
+            tcur += step;
+            const V3 pB = o + d * tcur;
+            tcur += step;
+            const V3 pvA = xform_point(C.w2v, pA), pvB = xform_point(C.w2v, pB);
+            bool inA, inB = j + 1 < nSamples;
+            if (C.volKind == PVOL_VOLUME_GRID) { inA = grid_density(S, pvA) != 0.f; inB = inB && grid_density(S, pvB) != 0.f; }
+            else { inA = box_inside(C.lo, C.hi, pvA); inB = inB && box_inside(C.lo, C.hi, pvB); }
+            if (!inA && !inB) continue;
+            bool occA = false, occB = false;
             for (int t = 0; t < C.nTris; ++t) {
                 const f4 r0 = *reinterpret_cast<const f4 *>(trows + 16 * t), r1 = *reinterpret_cast<const f4 *>(trows + 16 * t + 4),
                          r2 = *reinterpret_cast<const f4 *>(trows + 16 * t + 8), r3 = *reinterpret_cast<const f4 *>(trows + 16 * t + 12);
                 TriPre tp;
                 tp.p1 = v3(r0.x, r0.y, r0.z); tp.e1 = v3(r0.w, r1.x, r1.y); tp.e2 = v3(r1.z, r1.w, r2.x); tp.s1 = v3(r2.y, r2.z, r2.w);
                 tp.invDivisor = r3.x; tp.valid = r3.y != 0.f;
-#pragma unroll
-                for (int q = 0; q < TILE_COUNT_UNROLL; ++q) occ[q] = occ[q] | tri_test(tp, pp[q], ld, 0.f, INFINITY);
+                occA = occA | tri_test(tp, pA, ld, 0.f, INFINITY);
+                occB = occB | tri_test(tp, pB, ld, 0.f, INFINITY);
             }
-#pragma unroll
-            for (int q = 0; q < TILE_COUNT_UNROLL; ++q) u += (in[q] && !occ[q]) ? 1u : 0u;
+            u += ((inA && !occA) ? 1u : 0u) + ((inB && !occB) ? 1u : 0u);
         }
         return 4u + 7u * (uint32_t)nSamples + u;
     }

@@ -26,7 +26,7 @@
 // instead of running the exact wave-cooperative lookup inline, and li_fixup_kernel adds those terms afterwards
 // (lphoton(), always exact).  The hot kernel therefore carries neither lphoton's registers nor its LDS: three waves
 // per SIMD.
-#define GRP_CH 512    // rays per chunk (ordered by scatter_u, then cut into groups of 64)
+#define GRP_CH 512  // rays per chunk (ordered by scatter_u, then cut into groups of 64)
 #define GRP_CAP 256   // bucket capacity (photons)
 #define GRP_NW (GRP_CAP / 32)     // 32-bit mask words per lane
 #define GRP_BINS 64   // histogram bins over [0, T), 4-bit counters (eight per LDS word) + one overflow word

@@ -33,6 +33,9 @@
 #ifndef PVOL_FIXGRP_DEV_H
 #define PVOL_FIXGRP_DEV_H
 
+#ifndef FXG_CORE
+#define FXG_CORE 1   // photons that are members for every lookup of a cluster are summed once for the wave
+#endif
 #define FXG_CAP 4096   // bucket slots: photon indices only (4 B each), eight times nused 500
 #define FXG_MINI 8
 #define FXG_TRIES 16  // radius corrections per lookup before the exact pass takes it
@@ -322,6 +325,11 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             const bool doFlux = ok && (full || nIn >= 10);
             if (__ballot(doFlux)) {
                 int tq = tieQuota;
+                // photons that are members for EVERY lookup of the cluster are summed once for the wave after the scan (their
+                // indices wait in the histogram words, free by now): the 64 balls of a compact run overlap in most of their volume
+                const unsigned long long fluxLanes = __ballot(doFlux);
+                uint32_t *clist = hist;
+                int nCore = 0;
                 for (int i = 0; i < Mb; i += 8) {
                     FXG_FETCH8(i)
 #pragma unroll
@@ -330,7 +338,13 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                         const float d2 = dx * dx + dy * dy + dz * dz;
                         bool mem = doFlux && (i + u < Mb) && d2 < Tl && d2 < kth;
                         if (doFlux && (i + u < Mb) && d2 == kth && tq > 0) { mem = true; --tq; }
-                        if (!__ballot(mem)) continue;
+                        const unsigned long long mm = __ballot(mem);
+                        if (!mm) continue;
+                        if (FXG_CORE && mm == fluxLanes && nCore < 16 * LANES) {
+                            if (lane == 0) clist[nCore] = id_[u];
+                            ++nCore;
+                            continue;
+                        }
                         const float wgt = mem ? wIso : 0.f;
                         cf4 *row = (cf4 *)(S.alpha4 + (size_t)id_[u] * 8);
 #pragma unroll
@@ -340,6 +354,38 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                             acc[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, acc[4 * qq + 3]);
                         }
                     }
+                }
+                if (FXG_CORE && nCore > 0) {
+                    __syncthreads();
+                    // eight 128-B rows per load: lane l reads the (l & 7)-th float4 of the row of list entry 8 q + (l >> 3)
+                    const int sub = lane >> 3, quart = lane & 7;
+                    nf4 cs4 = {0.f, 0.f, 0.f, 0.f};
+                    for (int c0 = 0; c0 < nCore; c0 += 32) {
+                        nf4 v[4];
+#pragma unroll
+                        for (int qv = 0; qv < 4; ++qv) {
+                            const int at = c0 + 8 * qv + sub;
+                            const bool on = at < nCore;
+                            const uint32_t idx = clist[on ? at : 0];
+                            const float4 w = S.alpha4[(size_t)idx * 8 + quart];
+                            v[qv] = on ? nf4{w.x, w.y, w.z, w.w} : nf4{0.f, 0.f, 0.f, 0.f};
+                        }
+                        cs4 += (v[0] + v[1]) + (v[2] + v[3]);
+                    }
+                    float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {   // sum over the eight row groups (lane bits 3, 4, 5)
+                        float x = csv[cc];
+                        x += dppf<DPP_ROW_ROR8>(x);
+                        { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+                        { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+                        csv[cc] = x;
+                    }
+                    const float wCore = doFlux ? wIso : 0.f;
+#pragma unroll
+                    for (int b = 0; b < 30; ++b)
+                        acc[b] = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(csv[b & 3]), b >> 2)), wCore, acc[b]);
+                    __syncthreads();
                 }
             }
             FXG_T(cyFlux)

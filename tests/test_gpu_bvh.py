@@ -121,6 +121,15 @@ def _edge_scene(kind):
                               np.concatenate([p, p, p + 0.5], 1)]).astype(np.float32)          # a repeated vertex
         extra = np.concatenate([good, bad])
         extra = extra[rng.permutation(len(extra))]
+    elif kind == "with_spheres":   # hierarchy AND analytic spheres in one scene (closest hit takes the nearer of the two kinds)
+        extra = bumpy_ball(24, 12, (1.6, 1.0, 4.6), 0.5, 3)
+        sp = load_scene("sphereroom")
+        nm = len(s["mats.kind"])
+        for k in ("kind", "kd", "kr", "kt", "ior", "vn"):
+            s["mats." + k] = np.concatenate([s["mats." + k], sp["mats." + k]])
+        for k in ("o2w", "w2o", "f", "flip"):
+            s["spheres." + k] = sp["spheres." + k]
+        s["spheres.material"] = sp["spheres.material"] + nm
     else:
         extra = bumpy_ball(8, 5, (0.5, 1.3, 4.0), 0.8, 3)[:59]
     tris = np.concatenate([walls, extra]).astype(np.float32)
@@ -130,7 +139,7 @@ def _edge_scene(kind):
     return s, len(tris)
 
 
-@pytest.mark.parametrize("kind", ["dup", "flat", "just_over"])
+@pytest.mark.parametrize("kind", ["dup", "flat", "just_over", "with_spheres"])
 def test_hierarchy_edge_cases_equal_the_linear_scan(pvol, orc, kind):
     from test_gpu_render import _render
     import torch

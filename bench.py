@@ -293,6 +293,9 @@ def main():
     ap.add_argument("--driver", choices=["tile", "batch"], default="tile",
                     help="tile: whole SamplerRendererTasks on the device (LD sampler, camera, Li, film; pvol_render_tasks_device); "
                          "batch: Li() only over pre-built synthetic camera rays (pvol_li_batch_device)")
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks on ONE card (all on cuda:0, gloo for the collectives, the film staged through the host): "
+                         "exercises the partition, the film reduce and the rank reductions where no multi-GPU node is at hand; not a measurement")
     ap.add_argument("--save-image", default="", help="tile driver: write the resolved RGB film of the last step as .npy")
     args = ap.parse_args()
 
@@ -317,9 +320,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    rehearse = bool(args.rehearse_one_gpu) and world > 1
+    if rehearse:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     strong = world > 1 and not args.weak
@@ -366,7 +375,11 @@ def main():
         def step():
             d_pixels.zero_()
             pv.render_tasks(cam, film, smp, task_ids, d_pixels.data_ptr(), None, stream)
-            if strong:
+            if strong and rehearse:
+                host = d_pixels.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                d_pixels.copy_(host)
+            elif strong:
                 dist.all_reduce(d_pixels, op=dist.ReduceOp.SUM)   # the film reduce: 4 floats per pixel over RCCL
             pv.film_resolve(film, d_pixels.data_ptr(), d_rgb.data_ptr(), stream)
     else:
@@ -397,10 +410,11 @@ def main():
     dt = time.perf_counter() - t0
     pv.check_errors()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        rdev = torch.device("cpu") if rehearse else dev
+        t = torch.tensor([dt], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([n_rays], dtype=torch.float64, device=dev)
+        tot = torch.tensor([n_rays], dtype=torch.float64, device=rdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_rays = int(tot.item())
     else:
@@ -442,7 +456,8 @@ def main():
                                     n_tiles, total_rays),
                        "step": what,
                        "photon_map": "%s: %d photons (>= %d requested), built in %.1f s (outside the timed steps; see end_to_end)" % (photon_note, n_photons, args.photons, t_map),
-                       "partition": part + ", photon map replicated"},
+                       "partition": part + ", photon map replicated" +
+                                    (" -- REHEARSAL: all ranks on one card, gloo collectives, film staged through the host; not a measurement" if rehearse else "")},
             "wall_s": dt, "checksum": checksum,
             # BASELINE.json's metric is Msamples/s AND wall-clock: one frame end to end = photon shoot + search-structure build +
             # one render step (sampler/camera pre-pass, march + gather, film splat, film reduce, resolve)

@@ -1253,12 +1253,21 @@ __device__ void lite_ray(const DevScene &S, RayRec rec, int n, Rng &rng, float *
             for (int i = lane; i < n; i += LANES) lightNum[i] = van_der_corput((uint32_t)i, scramble);
             rng_skip<true>(rng, (unsigned long long)n, lane);
             __syncthreads();
-            for (int i = 0; i < n; ++i) {   // Shuffle(samples, n, 1), montecarlo.h:174-181
-                const uint32_t other = (uint32_t)i + (rng_uint<true>(rng, lane) % (uint32_t)(n - i));
-                if (lane == 0) {
-                    const float a = lightNum[i], b = lightNum[other];
-                    lightNum[i] = b;
-                    lightNum[other] = a;
+            // Shuffle(samples, n, 1), montecarlo.h:174-181: swap(samp[i], samp[i + RandomUInt() % (n - i)]) for i = 0 .. n-1.  The n draws
+            // and their remainders do not depend on the swaps: 64 at a time, one per lane (draw j of a batch lands in lane j, the
+            // stream order of the serial loop); only the swaps themselves stay a serial chain on lane 0.
+            for (int base = 0; base < n; base += LANES) {
+                const int cnt = min(LANES, n - base);
+                const uint32_t y = rng_bulk(rng, cnt, lane);
+                const int iMine = base + lane;
+                const uint32_t oth = lane < cnt ? (uint32_t)iMine + (y % (uint32_t)(n - iMine)) : 0u;
+                for (int j = 0; j < cnt; ++j) {
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)oth, j);
+                    if (lane == 0) {
+                        const float a = lightNum[base + j], b = lightNum[other];
+                        lightNum[base + j] = b;
+                        lightNum[other] = a;
+                    }
                 }
             }
             __syncthreads();

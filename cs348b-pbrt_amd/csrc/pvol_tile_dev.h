@@ -349,8 +349,11 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
                     const size_t rj = (size_t)st.first_ray + k + s0 + (uint32_t)j;
                     RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k + s0 + (uint32_t)j - begin)) * A.recStride, S.maxSteps, grid);
                     if (A.liteResolve) {   // no drawn value decides more than the light of a step: geometry one step per lane, then the RNG alone
-                        const int nSteps = geo_ray(S, A, pr, rec, lane, grid, blackS, blackMask);
-                        lite_ray(S, rec, nSteps, rng, M.lightNum, lane, grid, S.nLights);
+                        // PVOL_TILE_DEBUG timing knobs (results are wrong with any of them): 32 no visibility tests, 64 no lightNum
+                        // shuffle, 128 no RNG walk at all
+                        const int nSteps = geo_ray(S, A, pr, rec, lane, grid, (T.debugSkip & 32u) ? true : blackS, blackMask);
+                        if (T.debugSkip & 128u) rng_skip<true>(rng, 4ull + 7ull * (unsigned long long)nSteps, lane);
+                        else lite_ray(S, rec, nSteps, rng, M.lightNum, lane, grid, (T.debugSkip & 64u) ? 1 : S.nLights);
                     } else {
                         f4 Lv, Tr;
                         march_ray<false, MODE_RESOLVE, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);

@@ -499,12 +499,18 @@ __device__ bool march_ray(const DevScene &S, const LiArgs &A, const pvol_ray &pr
             for (int i = lane; i < nSamples; i += LANES) lightNum[i] = van_der_corput((uint32_t)i, scramble);
             rng_skip<RNGON>(rng, (unsigned long long)nSamples, lane);  // n one-element shuffles (montecarlo.h:308-309)
             __syncthreads();
-            for (int i = 0; i < nSamples; ++i) {                       // Shuffle(samples, n, 1), montecarlo.h:174-181
-                uint32_t other = (uint32_t)i + (rng_uint<RNGON>(rng, lane) % (uint32_t)(nSamples - i));
-                if (lane == 0) {
-                    float a = lightNum[i], b = lightNum[other];
-                    lightNum[i] = b;
-                    lightNum[other] = a;
+            for (int base = 0; base < nSamples; base += LANES) {       // Shuffle(samples, n, 1), montecarlo.h:174-181: draws and
+                const int cnt = min(LANES, nSamples - base);            // remainders 64 at a time (as lite_ray does), the swaps serial
+                const uint32_t y = rng_bulk(rng, cnt, lane);
+                const int iMine = base + lane;
+                const uint32_t oth = lane < cnt ? (uint32_t)iMine + (y % (uint32_t)(nSamples - iMine)) : 0u;
+                for (int j = 0; j < cnt; ++j) {
+                    const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)oth, j);
+                    if (lane == 0) {
+                        float a = lightNum[base + j], b = lightNum[other];
+                        lightNum[base + j] = b;
+                        lightNum[other] = a;
+                    }
                 }
             }
             __syncthreads();

@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(LANES) void li_geo_kernel(LiArgs A) {
 // The RNG side of one ray's Li() when no drawn value reaches a decision beyond the light choice: LDShuffleScrambled1D for
 // lightNum, one draw per step, one per unoccluded sample (A.1), 64 steps at a time.  Reads the masks geo_ray left, leaves the
 // light of every step (and the drawn tau offsets for a VolumeGrid).  Shared by li_resolve_lite_kernel and the tile pre-pass.
-__device__ void lite_ray(const DevScene &S, RayRec rec, int n, Rng &rng, float *lightNum, int lane, bool grid, int nLights) {
+__device__ void lite_ray(const DevScene &S, RayRec rec, int n, Rng &rng, float *lightNum, int lane, bool grid, int nLights, bool noSwaps = false) {
     if (n > 0) {
         // LDShuffleScrambled1D(1, n, lightNum) + (1, n, lightComp) + 2D(1, n, lightPos): 4 + 6n draws (photonvolume.cpp:137-142)
         if (nLights > 1) {
@@ -1267,7 +1267,7 @@ __device__ void lite_ray(const DevScene &S, RayRec rec, int n, Rng &rng, float *
                 const uint32_t y = rng_bulk(rng, cnt, lane);
                 const int iMine = base + lane;
                 const uint32_t oth = lane < cnt ? (uint32_t)iMine + (y % (uint32_t)(n - iMine)) : 0u;
-                for (int j = 0; j < cnt; ++j) {
+                for (int j = 0; j < (noSwaps ? 0 : cnt); ++j) {   // noSwaps: timing knob 256 of PVOL_TILE_DEBUG (wrong results)
                     const uint32_t other = (uint32_t)__builtin_amdgcn_readlane((int)oth, j);
                     if (lane == 0) {
                         const float a = lightNum[base + j], b = lightNum[other];

@@ -350,10 +350,10 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
                     RayRec rec = ray_rec(A.records + ((size_t)sidx * A.sliceM + (k + s0 + (uint32_t)j - begin)) * A.recStride, S.maxSteps, grid);
                     if (A.liteResolve) {   // no drawn value decides more than the light of a step: geometry one step per lane, then the RNG alone
                         // PVOL_TILE_DEBUG timing knobs (results are wrong with any of them): 32 no visibility tests, 64 no lightNum
-                        // shuffle, 128 no RNG walk at all
+                        // shuffle, 128 no RNG walk at all, 256 the shuffle's draws without its swaps
                         const int nSteps = geo_ray(S, A, pr, rec, lane, grid, (T.debugSkip & 32u) ? true : blackS, blackMask);
                         if (T.debugSkip & 128u) rng_skip<true>(rng, 4ull + 7ull * (unsigned long long)nSteps, lane);
-                        else lite_ray(S, rec, nSteps, rng, M.lightNum, lane, grid, (T.debugSkip & 64u) ? 1 : S.nLights);
+                        else lite_ray(S, rec, nSteps, rng, M.lightNum, lane, grid, (T.debugSkip & 64u) ? 1 : S.nLights, (T.debugSkip & 256u) != 0u);
                     } else {
                         f4 Lv, Tr;
                         march_ray<false, MODE_RESOLVE, NREG>(S, A, pr, rng, M, lane, wc, &Lv, &Tr, rec);

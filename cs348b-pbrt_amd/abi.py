@@ -262,7 +262,8 @@ class RenderDebug(C.Structure):
 
 class SurfaceParams(C.Structure):   # pvol_surface_params
     _fields_ = [("n_used", C.c_int32), ("max_dist", C.c_float), ("max_specular_depth", C.c_int32), ("final_gather", C.c_int32),
-                ("n_caustic_paths", C.c_uint32), ("use_preprocess_store", C.c_int32), ("reserved", C.c_uint32 * 2)]
+                ("n_caustic_paths", C.c_uint32), ("use_preprocess_store", C.c_int32), ("n_indirect_photons", C.c_uint32),
+                ("reserved", C.c_uint32 * 1)]
 
 
 def make_camera(raster_to_camera, camera_to_world, shutter_open=0.0, shutter_close=1.0, lens_radius=0.0, focal_distance=1e30):

@@ -302,7 +302,9 @@ int pvol_set_scene(pvol_ctx *c, const pvol_scene *s) {
     h.candCap = ((c->params.n_used + 63) / 64) * 64 + 192;
     // march-step bound: diagonal of the volume's world bound / stepSize (rays are clipped to the extent)
     h.maxSteps = 0;
-    if ((s->n_lights > 1 || v.kind == PVOL_VOLUME_GRID) && v.kind != PVOL_VOLUME_NONE) {
+    // (every scene with a medium: a one-light homogeneous scene reaches the record plan too -- pvol_li with the caller's live
+    // RNG state takes the RESOLVE + REPLAY path -- and with maxSteps 0 every such ray was reported as PVOL_E_LIMIT)
+    if (v.kind != PVOL_VOLUME_NONE) {
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = 0; k < 8; ++k) {
             float x = (k & 1) ? v.extent_max[0] : v.extent_min[0], y = (k & 2) ? v.extent_max[1] : v.extent_min[1],
@@ -525,6 +527,15 @@ int pvol_set_surface_integrator(pvol_ctx *c, const pvol_surface_params *sp, cons
     // the matte subset: a specular BSDF would need the recursion of SpecularReflect / SpecularTransmit (core/integrator.cpp:177-262)
     for (size_t i = 0; i < c->triMatHost.size(); ++i)
         if (c->hsh.mats[c->triMatHost[i]].kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
+    // an indirect map makes PhotonIntegrator::Li gather: the final gather, or LPhoton(indirectMap) with 144 more rho draws
+    // (photonmap.cpp:183-309).  None of that radiance and none of those draws exist here yet, so such an integrator is
+    // refused by name rather than rendered wrong -- whether the map is the caller's (n_indirect_photons) or the store of
+    // the last pvol_preprocess.
+    if (sp->n_indirect_photons > 0) return PVOL_E_UNSUPPORTED;
+    if (sp->use_preprocess_store) {
+        if (!c->surfKept) return PVOL_E_INVALID;   // nothing was kept: params.keep_surface_photons was 0, or no pvol_preprocess yet
+        if (c->surf[2].n > 0) return PVOL_E_UNSUPPORTED;
+    }
     uint32_t nPaths = sp->n_caustic_paths;
     std::vector<float> hp;
     const float *dP = 0, *dWo = 0, *dAlpha = 0;

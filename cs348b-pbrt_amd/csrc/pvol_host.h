@@ -112,6 +112,7 @@ struct pvol_ctx {
     uint64_t shootStats[12];
     // surface stores of the last pvol_preprocess (kept only with params.keep_surface_photons): kind 0 caustic, 1 direct, 2 indirect
     struct SurfStore { float *p = 0, *wo = 0, *alpha = 0; uint32_t n = 0, nPaths = 0; } surf[3];
+    bool surfKept = false;   // the last pvol_preprocess ran with keep_surface_photons and left its stores here
     float *dRad = 0;       // radiance photons: [n][8] = p(3) n(3) material index, pad
     uint32_t nRad = 0;
     // caustic map of the surface integrator (pvol_set_surface_integrator), same cell layout as the volume map

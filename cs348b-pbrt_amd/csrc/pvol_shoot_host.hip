@@ -96,6 +96,7 @@ extern "C" void pvol_free_surface_stores(pvol_ctx *c) {
         c->surf[k] = pvol_ctx::SurfStore();
     }
     hipFree(c->dRad); c->dRad = 0; c->nRad = 0;
+    c->surfKept = false;
 }
 
 extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
@@ -323,6 +324,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
         }
         c->dRad = B.rad.d; c->nRad = (uint32_t)nRadTotal;
         B.rad.d = 0;
+        c->surfKept = true;
     }
     if (rc != PVOL_OK || nVolume == 0) {
         B.release(false);

@@ -15,6 +15,7 @@
 struct SurfHit {
     int tri, mat;
     float t;
+    float rayEps;   // Intersection::rayEpsilon: 1e-3 t for a triangle (trianglemesh.cpp:205), 5e-4 t for a sphere (sphere.cpp:155)
     V3 p, nn;
 };
 // Scene::Intersect for one lane: closest hit, the later triangle on equal t (as the linear scans of this library and its oracle),
@@ -54,6 +55,7 @@ __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit 
             h->tri = -1 - si;
             h->mat = S.spheres[si].mat;
             h->t = mt;
+            h->rayEps = 5e-4f * mt;
             sphere_dg(S.spheres[si], ph, &h->p, &dpduW, &h->nn);
             return true;
         }
@@ -66,6 +68,7 @@ __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit 
     const V3 dpdv = (dp1 * (-du2) + dp2 * du1) * invdet;
     h->tri = best;
     h->t = mt;
+    h->rayEps = 1e-3f * mt;
     h->p = o + d * mt;
     h->nn = normalize(cross(dpdu, dpdv));
     if (flip) h->nn = h->nn * -1.f;
@@ -115,7 +118,7 @@ __device__ uint32_t surf_count_draws(const DevScene &S, const SurfHit &h, V3 d, 
     const bool lambert = m.kind == PVOL_MATERIAL_MATTE && m.nBxdf > 0;   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd
     const V3 wo = -d;
     uint32_t n = 0;
-    for (int ln = 0; ln < S.nLights; ++ln) n += surf_light(S, ln, h.p, 1e-3f * h.t, h.nn, wo, lambert, blackMask).take ? 1u : 0u;
+    for (int ln = 0; ln < S.nLights; ++ln) n += surf_light(S, ln, h.p, h.rayEps, h.nn, wo, lambert, blackMask).take ? 1u : 0u;
     if (S.surf.nPhotons > 0u && lambert) n += 144u;     // LPhoton(causticMap): two BSDF::rho(wo, rng)
     if (0 + 1 < S.surf.maxSpecularDepth) n += 6u;       // SpecularReflect + SpecularTransmit: BSDFSample(rng) each
     return n;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
         const pvol_ray pr = A.rays[have ? ri : 0];
         const V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
         SurfHit h;
-        h.tri = 0; h.mat = 0; h.t = 0.f; h.p = h.nn = v3(0.f, 0.f, 0.f);
+        h.tri = 0; h.mat = 0; h.t = 0.f; h.rayEps = 0.f; h.p = h.nn = v3(0.f, 0.f, 0.f);
         const bool hit = have && surf_closest(S, o, d, pr.mint, &h);   // the ray's maxt is this very t (the tile pre-pass clipped it)
         float Ls[32];
 #pragma unroll
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
         // ---- direct lighting: Ld = f * Li * (AbsDot(wi, n) / pdf), Li = light radiance * Transmittance of the shadow ray
         if (lambert) {
             for (int ln = 0; ln < S.nLights; ++ln) {
-                const SurfLight sl = surf_light(S, ln, h.p, 1e-3f * h.t, h.nn, wo, true, blackMask);
+                const SurfLight sl = surf_light(S, ln, h.p, h.rayEps, h.nn, wo, true, blackMask);
                 if (!sl.take) continue;
                 float lenAB = 0.f;   // tau of the analytic medium along the shadow ray (homogeneous.h:80-84)
                 if (S.volKind != PVOL_VOLUME_NONE) {

@@ -229,7 +229,10 @@ extern "C" int pvol_render_tasks_device(pvol_ctx *c, const pvol_camera *camera, 
     memcpy(T.n1d, smp->n1d, sizeof(T.n1d));
     memcpy(T.n2d, smp->n2d, sizeof(T.n2d));
     T.scatterIndex = smp->scatter_index;
+#ifdef PVOL_TIMING_KNOBS   // timing experiments only (tools/tile_debug_*.sh build with it): every knob gives WRONG images and stream
+                           // positions, so the shipped library does not read the variable at all
     if (const char *dbg = getenv("PVOL_TILE_DEBUG")) T.debugSkip = (uint32_t)atoi(dbg);
+#endif
 
     // batches of tasks bounded by the work-buffer budget (rays 48 B + xy 8 B + XYZ 16 B per sample)
     size_t batchRays = (size_t)256 << 20;

@@ -660,12 +660,14 @@ def load(path):
     sp, vp = b.surf[1], b.vol[1]
     # PhotonVolumeIntegrator (integrators/photonvolume.cpp:224-229) and CreatePhotonShooter (core/photonshooter.cpp:529-548)
     d["params.f"] = np.array([vp.f("stepsize", 1.0), vp.f("maxdist", 0.1), sp.f("stepsize", 0.1)], F)
-    d["params.i"] = np.array([vp.i("nused", 50), vp.i("volumephotons", 0), sp.i("maxphotondepth", 5), sp.i("causticphotons", 20000),
+    # nused: the VOLUME integrator's default is 250 (photonvolume.cpp:226); 50 is the surface integrator's (photonmap.cpp:323)
+    d["params.i"] = np.array([vp.i("nused", 250), vp.i("volumephotons", 0), sp.i("maxphotondepth", 5), sp.i("causticphotons", 20000),
                               sp.i("indirectphotons", 10000), int(sp.b("finalgather", True))], np.int32)
     # the surface integrator's own parameters (integrators/photonmap.cpp:336-363) for pvol_set_surface_integrator
     d["surf.name"] = b.surf[0]
-    d["surf.params.f"] = np.array([sp.f("maxdist", 0.1)], F)
-    d["surf.params.i"] = np.array([sp.i("nused", 50), sp.i("maxspeculardepth", 5), int(sp.b("finalgather", True))], np.int32)
+    d["surf.params.i"] = np.array([sp.i("nused", 50), sp.i("maxspeculardepth", 5), int(sp.b("finalgather", True)),
+                                   sp.i("finalgathersamples", 32)], np.int32)
+    d["surf.params.f"] = np.array([sp.f("maxdist", 0.1), sp.f("gatherangle", 10.0)], F)
     d["camera.c2w"] = _mat16(b.camera["c2w"].m)
     d["camera.fov"] = np.array([b.camera["fov"]], F)
     d["film"] = np.array([b.film[0], b.film[1], b.spp], np.int32)

@@ -215,7 +215,7 @@ class PhotonVolume:
                                               d_pixels, C.byref(debug) if debug is not None else None, hip_stream), "pvol_render_tasks_device")
 
     def set_surface_integrator(self, n_used=50, max_dist=0.1, max_specular_depth=5, final_gather=False, caustic=None, n_paths=0,
-                               from_preprocess=False, off=False):
+                               from_preprocess=False, off=False, n_indirect=0):
         """PhotonIntegrator in front of the volume term (CreatePhotonMapSurfaceIntegrator, photonmap.cpp:336-363: nused 50,
         maxdist .1, maxspeculardepth 5).  `caustic` = (p[n,3], wo[n,3], alpha[n,30]) with `n_paths`, or from_preprocess=True to
         take the caustic photons the last preprocess() kept; off=True disables."""
@@ -225,6 +225,7 @@ class PhotonVolume:
         sp = abi.SurfaceParams()
         sp.n_used, sp.max_dist, sp.max_specular_depth, sp.final_gather = int(n_used), float(max_dist), int(max_specular_depth), int(bool(final_gather))
         sp.n_caustic_paths, sp.use_preprocess_store = int(n_paths), int(bool(from_preprocess))
+        sp.n_indirect_photons = int(n_indirect)   # the integrator's indirect map, if it has one: refused (PVOL_E_UNSUPPORTED)
         if caustic is None or from_preprocess:
             _check(lib().pvol_set_surface_integrator(self._h, C.byref(sp), None, None, None, 0), "pvol_set_surface_integrator")
             return

@@ -249,11 +249,13 @@ typedef struct pvol_surface_params {
     int32_t n_used;              /* "nused" (photonmap.cpp:340), lookup size of the caustic estimate */
     float max_dist;              /* "maxdist" (photonmap.cpp:345)                                    */
     int32_t max_specular_depth;  /* "maxspeculardepth" (photonmap.cpp:341): > 1 costs 6 draws per hit */
-    int32_t final_gather;        /* accepted for completeness: without an indirect map it changes nothing */
+    int32_t final_gather;        /* "finalgather": without an indirect map it changes nothing              */
     uint32_t n_caustic_paths;    /* nCausticPaths (photonshooter.cpp:215) of the map passed along    */
     int32_t use_preprocess_store;/* 1: take the caustic photons (and path count) the last pvol_preprocess kept
                                     (params.keep_surface_photons) instead of the arrays passed        */
-    uint32_t reserved[2];
+    uint32_t n_indirect_photons; /* photons in the integrator's INDIRECT map (0 with `indirectphotons 0`, both BASELINE
+                                    scenes).  > 0 makes Li() gather (photonmap.cpp:183-309): PVOL_E_UNSUPPORTED            */
+    uint32_t reserved[1];
 } pvol_surface_params;
 
 typedef struct pvol_ctx pvol_ctx;
@@ -402,10 +404,12 @@ int pvol_render_tasks_device(pvol_ctx *ctx, const pvol_camera *camera, const pvo
  * SamplerRendererTask::Run then computes Ls = surface Li, and the film receives T * Ls + Lvi
  * (samplerrenderer.cpp:95-97,239-251).  p/wo/alpha: the caustic map's n photons (p 3, wo 3, alpha 30
  * floats each; n == 0: no caustic map, as when the shooter stored no caustic photon).
- * PVOL_E_UNSUPPORTED: a triangle of the scene carries a non-matte material (here), or the volume /
+ * PVOL_E_UNSUPPORTED: a triangle of the scene carries a non-matte material, or an indirect photon map exists
+ * (sp->n_indirect_photons > 0, or use_preprocess_store and the shooter kept indirect photons) (here), or the volume /
  * nused lie outside li_group_kernel's domain (from pvol_render_tasks_device).  A
  * lookup with more than 2048 caustic photons within maxdist of ONE hit point is counted as an error
- * (pvol_check_errors), never truncated.  pvol_set_scene disables the surface integrator again. */
+ * (pvol_check_errors), never truncated.  PVOL_E_INVALID: use_preprocess_store without a pvol_preprocess that ran with
+ * params.keep_surface_photons.  pvol_set_scene disables the surface integrator again. */
 int pvol_set_surface_integrator(pvol_ctx *ctx, const pvol_surface_params *sp, const float *p, const float *wo,
                                 const float *alpha, uint32_t n);
 

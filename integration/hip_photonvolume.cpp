@@ -31,6 +31,10 @@
 #include "primitive.h"
 #include "shape.h"
 #include "camera.h"
+#include "accelerators/bvh.h"
+#include "accelerators/grid.h"
+#include "accelerators/kdtreeaccel.h"
+#include "photonshooter.h"
 #include "shapes/trianglemesh.h"
 #include "shapes/sphere.h"
 #include "lights/distant.h"
@@ -51,15 +55,16 @@
 #undef protected
 
 #include "pvol.h"
+#include "hip_flatten.h"   // HipFlattenScene: Scene -> pvol_scene (CPU-tested against the reference's own scenes, oracle/)
 
-namespace {
-void putSpec(pvol_spectrum *d, const Spectrum &s) { for (int i = 0; i < PVOL_NBINS; ++i) d->c[i] = s.c[i]; }
-void putMat(float *d, const Matrix4x4 &m) { for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) d[4 * r + c] = m.m[r][c]; }
-}
+using hipflat::putMat;
 
 class HipPhotonVolumeIntegrator : public VolumeIntegrator {
 public:
-    HipPhotonVolumeIntegrator(const pvol_params &p) : params(p), ctx(NULL), tauSampleOffset(0), scatterSampleOffset(0) {
+    // `shooter` != NULL: take the volume map the reference's own PhotonShooter built (its Preprocess runs before ours,
+    // renderers/samplerrenderer.cpp:194-196) instead of shooting on the device -- the oracle-identical map.
+    HipPhotonVolumeIntegrator(const pvol_params &p, const PhotonShooter *shooter = NULL)
+        : params(p), ctx(NULL), mapSource(shooter), tauSampleOffset(0), scatterSampleOffset(0) {
         if (pvol_create(&params, &ctx) != PVOL_OK) Severe("photonvolume_hip: no usable HIP device");
     }
     ~HipPhotonVolumeIntegrator() { pvol_destroy(ctx); }
@@ -72,69 +77,37 @@ public:
 
     // core/integrator.h:55-57 hook; replaces PhotonShooter::Preprocess for the volume map
     void Preprocess(const Scene *scene, const Camera *, const Renderer *) {
-        std::vector<pvol_light> lights;
-        std::vector<pvol_triangle> tris;
-        std::vector<pvol_sphere> spheres;
-        std::vector<pvol_material> mats;
-        std::map<const Material *, int> matIndex;
-        pvol_scene s;
-        memset(&s, 0, sizeof(s));
-        flattenVolume(scene->volumeRegion, &s.volume);
-        for (size_t i = 0; i < scene->lights.size(); ++i) lights.push_back(flattenLight(scene->lights[i]));
-        // fully refined primitives of the aggregate (the configs use GeometricPrimitive(Triangle, matte|glass))
-        vector<Reference<Primitive> > leaves;
-        scene->aggregate->FullyRefine(leaves);
-        for (size_t i = 0; i < leaves.size(); ++i) {
-            const GeometricPrimitive *gp = dynamic_cast<const GeometricPrimitive *>(leaves[i].GetPtr());
-            const Triangle *tri = gp ? dynamic_cast<const Triangle *>(gp->shape.GetPtr()) : NULL;
-            const Sphere *sph = gp ? dynamic_cast<const Sphere *>(gp->shape.GetPtr()) : NULL;
-            if (!tri && !sph) Severe("photonvolume_hip: only triangle meshes and spheres are supported on the photon path");
-            const Material *m = gp->material.GetPtr();
-            if (!matIndex.count(m)) { matIndex[m] = (int)mats.size(); mats.push_back(flattenMaterial(m)); }
-            if (sph) {   // shapes/sphere.cpp:41-49: what the constructor stored
-                pvol_sphere q;
-                for (int r = 0; r < 4; ++r)
-                    for (int c = 0; c < 4; ++c) {
-                        q.object_to_world[4 * r + c] = sph->ObjectToWorld->m.m[r][c];
-                        q.world_to_object[4 * r + c] = sph->WorldToObject->m.m[r][c];
-                    }
-                q.radius = sph->radius; q.z_min = sph->zmin; q.z_max = sph->zmax;
-                q.theta_min = sph->thetaMin; q.theta_max = sph->thetaMax; q.phi_max = sph->phiMax;
-                q.material = matIndex[m];
-                q.flip_normal = (sph->ReverseOrientation ^ sph->TransformSwapsHandedness) ? 1 : 0;
-                spheres.push_back(q);
-                continue;
-            }
-            pvol_triangle t;
-            for (int k = 0; k < 3; ++k) {
-                const Point &p = tri->mesh->p[tri->v[k]];
-                t.p[k][0] = p.x; t.p[k][1] = p.y; t.p[k][2] = p.z;
-            }
-            t.material = matIndex[m];
-            t.flip_normal = (tri->ReverseOrientation ^ tri->TransformSwapsHandedness) ? 1 : 0;
-            tris.push_back(t);
+        HipFlatScene flat;
+        const char *why = HipFlattenScene(scene, &flat);
+        if (why) Severe("photonvolume_hip: %s", why);
+        int rc = pvol_set_scene(ctx, &flat.scene);
+        if (rc != PVOL_OK) Severe("photonvolume_hip: pvol_set_scene: %s", pvol_strerror(rc));
+        if (mapSource) {   // `volumeMap = new KdTree<Photon>(volumePhotons)` already happened (photonshooter.cpp:502-503)
+            const KdTree<Photon> *map = mapSource->volumeMap;
+            rc = UploadPhotons(map ? map->nodeData : NULL, map ? map->nNodes : 0);
+            if (rc != PVOL_OK) Severe("photonvolume_hip: pvol_upload_photons: %s", pvol_strerror(rc));
+            return;
         }
-        s.n_lights = (uint32_t)lights.size(); s.lights = lights.empty() ? NULL : &lights[0];
-        s.n_triangles = (uint32_t)tris.size(); s.triangles = tris.empty() ? NULL : &tris[0];
-        s.n_materials = (uint32_t)mats.size(); s.materials = mats.empty() ? NULL : &mats[0];
-        s.n_spheres = (uint32_t)spheres.size(); s.spheres = spheres.empty() ? NULL : &spheres[0];
-        const BBox &wb = scene->WorldBound();
-        s.world_min[0] = wb.pMin.x; s.world_min[1] = wb.pMin.y; s.world_min[2] = wb.pMin.z;
-        s.world_max[0] = wb.pMax.x; s.world_max[1] = wb.pMax.y; s.world_max[2] = wb.pMax.z;
-        putSpec(&s.cie_x, SampledSpectrum::X); putSpec(&s.cie_y, SampledSpectrum::Y); putSpec(&s.cie_z, SampledSpectrum::Z);
-        s.xyz_scale = float(sampledLambdaEnd - sampledLambdaStart) / float(CIE_Y_integral * nSpectralSamples);
-        int rc = pvol_set_scene(ctx, &s);
-        if (rc != PVOL_OK) Severe("photonvolume_hip: %s", pvol_strerror(rc));
         // photon shoot + search-structure build on the device; NumSystemCores() virtual tasks would mimic a
         // CPU run, a GPU wants thousands.
         // NOTE: an unchanged SamplerRenderer still runs the reference's own PhotonShooter::Preprocess when the SURFACE
         // integrator is "photonmap" (core/api.cpp:1225-1230, samplerrenderer.cpp:194-196), so its CPU shooter also fills a
-        // volume map nobody reads; set that integrator's "volumephotons" to 0 in the scene (the shooter's volume store is
-        // driven by the VolumeIntegrator's parameter of the same name) or see INTEGRATION.md for taking the map from it
-        // with pvol_upload_photons instead of shooting here.
+        // volume map nobody reads; have the "photonvolume_hip" branch pass the shooter "volumephotons" 0, or construct this
+        // integrator with the shooter (`"bool deviceshoot" false`) to take its map instead of shooting here.
         rc = pvol_preprocess(ctx, 16384);
         if (rc == PVOL_E_SHOOT_FAILED) Error("Unable to store enough photons.  Giving up.\n");   // photonshooter.cpp:292
-        else if (rc != PVOL_OK) Severe("photonvolume_hip: %s", pvol_strerror(rc));
+        else if (rc != PVOL_OK) Severe("photonvolume_hip: pvol_preprocess: %s", pvol_strerror(rc));
+    }
+
+    // Photon records (core/photonshooter.h:20-27, 152-B AoS) -> the three SoA arrays of pvol_upload_photons.
+    int UploadPhotons(const Photon *ph, uint32_t n) {
+        std::vector<float> p(3 * (size_t)n), wi(3 * (size_t)n), alpha((size_t)PVOL_NBINS * n);
+        for (uint32_t i = 0; i < n; ++i) {
+            p[3 * i] = ph[i].p.x; p[3 * i + 1] = ph[i].p.y; p[3 * i + 2] = ph[i].p.z;
+            wi[3 * i] = ph[i].wi.x; wi[3 * i + 1] = ph[i].wi.y; wi[3 * i + 2] = ph[i].wi.z;
+            for (int b = 0; b < PVOL_NBINS; ++b) alpha[(size_t)PVOL_NBINS * i + b] = ph[i].alpha.c[b];
+        }
+        return pvol_upload_photons(ctx, n ? &p[0] : NULL, n ? &wi[0] : NULL, n ? &alpha[0] : NULL, n);
     }
 
     // integrators/photonvolume.cpp:112-222 through the per-sample entry point: the caller's RNG goes in and
@@ -149,7 +122,7 @@ public:
         int32_t mti = rng.mti;
         float Lv[PVOL_NBINS], Tr[PVOL_NBINS];
         int rc = pvol_li(ctx, &r, mt, &mti, Lv, Tr);
-        if (rc != PVOL_OK) Severe("photonvolume_hip: %s", pvol_strerror(rc));
+        if (rc != PVOL_OK) Severe("photonvolume_hip: pvol_li: %s", pvol_strerror(rc));
         for (int i = 0; i < PVOL_MT_N; ++i) rng.mt[i] = mt[i];
         rng.mti = mti;
         Spectrum L(0.f);
@@ -171,78 +144,16 @@ public:
         return Exp(-scene->volumeRegion->tau(ray, step, offset));
     }
 
-private:
-    static void fillRay(const Ray &ray, pvol_ray *r) {
-        memset(r, 0, sizeof(*r));
-        r->o[0] = ray.o.x; r->o[1] = ray.o.y; r->o[2] = ray.o.z;
-        r->d[0] = ray.d.x; r->d[1] = ray.d.y; r->d[2] = ray.d.z;
-        r->mint = ray.mint; r->maxt = ray.maxt; r->time = ray.time;
-    }
-    static void flattenVolume(const VolumeRegion *vr, pvol_volume *v) {
-        memset(v, 0, sizeof(*v));
-        if (!vr) { v->kind = PVOL_VOLUME_NONE; return; }
-        const BBox *e = NULL;
-        const Transform *w2v = NULL;
-        if (const VolumeGridDensity *g = dynamic_cast<const VolumeGridDensity *>(vr)) {
-            v->kind = PVOL_VOLUME_GRID; e = &g->extent; w2v = &g->WorldToVolume;
-            putSpec(&v->sigma_a, g->sig_a); putSpec(&v->sigma_s, g->sig_s); putSpec(&v->le, g->le); v->g = g->g;
-            v->nx = g->nx; v->ny = g->ny; v->nz = g->nz; v->density = g->density;
-        } else if (const HomogeneousVolumeDensity *h = dynamic_cast<const HomogeneousVolumeDensity *>(vr)) {
-            v->kind = dynamic_cast<const RainbowVolume *>(vr) ? PVOL_VOLUME_RAINBOW : PVOL_VOLUME_HOMOGENEOUS;
-            e = &h->extent; w2v = &h->WorldToVolume;
-            putSpec(&v->sigma_a, h->sig_a); putSpec(&v->sigma_s, h->sig_s); putSpec(&v->le, h->le); v->g = h->g;
-        } else {
-            Severe("photonvolume_hip: volume kind not supported (homogeneous, rainbow, volumegrid)");
-        }
-        v->extent_min[0] = e->pMin.x; v->extent_min[1] = e->pMin.y; v->extent_min[2] = e->pMin.z;
-        v->extent_max[0] = e->pMax.x; v->extent_max[1] = e->pMax.y; v->extent_max[2] = e->pMax.z;
-        putMat(v->world_to_volume, w2v->m);
-        putMat(v->volume_to_world, w2v->mInv);
-    }
-    static pvol_light flattenLight(const Light *L) {
-        pvol_light l;
-        memset(&l, 0, sizeof(l));
-        putMat(l.light_to_world, L->LightToWorld.m);
-        putMat(l.world_to_light, L->WorldToLight.m);
-        if (const DistantLight *d = dynamic_cast<const DistantLight *>(L)) {
-            l.kind = PVOL_LIGHT_DISTANT; l.dir[0] = d->lightDir.x; l.dir[1] = d->lightDir.y; l.dir[2] = d->lightDir.z;
-            putSpec(&l.intensity, d->L);
-        } else if (const SpotLight *s = dynamic_cast<const SpotLight *>(L)) {
-            l.kind = PVOL_LIGHT_SPOT; l.pos[0] = s->lightPos.x; l.pos[1] = s->lightPos.y; l.pos[2] = s->lightPos.z;
-            putSpec(&l.intensity, s->Intensity); l.cos_total_width = s->cosTotalWidth; l.cos_falloff_start = s->cosFalloffStart;
-        } else if (const PointLight *p = dynamic_cast<const PointLight *>(L)) {
-            l.kind = PVOL_LIGHT_POINT; l.pos[0] = p->lightPos.x; l.pos[1] = p->lightPos.y; l.pos[2] = p->lightPos.z;
-            putSpec(&l.intensity, p->Intensity);
-        } else {
-            Severe("photonvolume_hip: light kind not supported (point, spot, distant)");
-        }
-        return l;
-    }
-    static pvol_material flattenMaterial(const Material *m) {
-        pvol_material o;
-        memset(&o, 0, sizeof(o));
-        DifferentialGeometry dg;   // constant textures ignore it
-        if (const MatteMaterial *mm = dynamic_cast<const MatteMaterial *>(m)) {
-            o.kind = PVOL_MATERIAL_MATTE;
-            putSpec(&o.kd, mm->Kd->Evaluate(dg).Clamp());
-        } else if (const GlassMaterial *gm = dynamic_cast<const GlassMaterial *>(m)) {
-            o.kind = PVOL_MATERIAL_GLASS;
-            putSpec(&o.kr, gm->Kr->Evaluate(dg).Clamp());
-            putSpec(&o.kt, gm->Kt->Evaluate(dg).Clamp());
-            o.ior = gm->index->Evaluate(dg);
-            o.vn = gm->Vn;
-        } else {
-            Severe("photonvolume_hip: material not supported on the photon path (matte, glass)");
-        }
-        return o;
-    }
+    pvol_ctx *context() const { return ctx; }
+    int TauSampleOffset() const { return tauSampleOffset; }
+    int ScatterSampleOffset() const { return scatterSampleOffset; }
 
     // Tile driver (include/pvol.h): what a renderer calls INSTEAD of enqueueing SamplerRendererTasks
     // (renderers/samplerrenderer.cpp:206-221) when the camera is a pinhole PerspectiveCamera, the film an ImageFilm, the
     // sampler an LDSampler and the surface integrator contributes nothing.  d_pixels / d_rgb are device buffers
     // (x*y*4 and x*y*3 floats, d_pixels zeroed); the resolved RGB then goes through ::WriteImage as before.
     int RenderTasks(const PerspectiveCamera *camera, const ImageFilm *film, const LDSampler *sampler, const Sample *origSample,
-                    int nTasks, float *d_pixels, float *d_rgb, void *hipStream) const {
+                    int nTasks, float *d_pixels, float *d_rgb, void *hipStream, const std::vector<uint32_t> *taskList = NULL) const {
         pvol_camera cam;
         memset(&cam, 0, sizeof(cam));
         putMat(cam.raster_to_camera, camera->RasterToCamera.m);
@@ -264,22 +175,33 @@ private:
         for (uint32_t i = 0; i < smp.n1d_count; ++i) smp.n1d[i] = origSample->n1D[i];
         for (uint32_t i = 0; i < smp.n2d_count; ++i) smp.n2d[i] = origSample->n2D[i];
         smp.tau_index = tauSampleOffset; smp.scatter_index = scatterSampleOffset;
-        std::vector<uint32_t> tasks(nTasks);
-        for (int t = 0; t < nTasks; ++t) tasks[t] = t;
-        int rc = pvol_render_tasks_device(ctx, &cam, &f, &smp, tasks.data(), nTasks, d_pixels, NULL, hipStream);
+        std::vector<uint32_t> tasks;   // all of them, or the caller's share (one rank of a multi-GPU render)
+        if (taskList) tasks = *taskList;
+        else for (int t = 0; t < nTasks; ++t) tasks.push_back(t);
+        int rc = pvol_render_tasks_device(ctx, &cam, &f, &smp, tasks.empty() ? NULL : &tasks[0], (uint32_t)tasks.size(), d_pixels, NULL, hipStream);
         if (rc == PVOL_OK) rc = pvol_film_resolve_device(ctx, &f, d_pixels, d_rgb, hipStream);
         return rc;
     }
 
+private:
+    static void fillRay(const Ray &ray, pvol_ray *r) {
+        memset(r, 0, sizeof(*r));
+        r->o[0] = ray.o.x; r->o[1] = ray.o.y; r->o[2] = ray.o.z;
+        r->d[0] = ray.d.x; r->d[1] = ray.d.y; r->d[2] = ray.d.z;
+        r->mint = ray.mint; r->maxt = ray.maxt; r->time = ray.time;
+    }
     pvol_params params;
     pvol_ctx *ctx;
+    const PhotonShooter *mapSource;
     int tauSampleOffset, scatterSampleOffset;
 };
 
 // core/api.cpp:572-581 calls this for "photonvolume_hip"; surfparams carries the shooter's
 // stepsize/maxphotondepth/causticphotons/indirectphotons/finalgather exactly as CreatePhotonShooter reads them
 // (core/photonshooter.cpp:529-548), volparams the integrator's (integrators/photonvolume.cpp:224-229).
-VolumeIntegrator *CreateHipPhotonVolumeIntegrator(const ParamSet &volparams, const ParamSet &surfparams) {
+// `psh` is the renderer's shooter (core/api.cpp:1225-1230 hands it to both integrators); it is only read when the scene says
+// `"bool deviceshoot" false`.
+VolumeIntegrator *CreateHipPhotonVolumeIntegrator(const ParamSet &volparams, const ParamSet &surfparams, PhotonShooter *psh) {
     pvol_params p;
     pvol_default_params(&p);
     p.step_size = volparams.FindOneFloat("stepsize", 1.f);
@@ -292,5 +214,6 @@ VolumeIntegrator *CreateHipPhotonVolumeIntegrator(const ParamSet &volparams, con
     p.n_indirect_photons = surfparams.FindOneInt("indirectphotons", 10000);
     p.final_gather = surfparams.FindOneBool("finalgather", true) ? 1 : 0;
     if (PbrtOptions.quickRender) { p.n_caustic_photons /= 10; p.n_indirect_photons /= 10; }
-    return new HipPhotonVolumeIntegrator(p);
+    const bool deviceShoot = volparams.FindOneBool("deviceshoot", true);
+    return new HipPhotonVolumeIntegrator(p, deviceShoot ? NULL : psh);
 }

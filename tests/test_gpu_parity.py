@@ -69,10 +69,13 @@ def test_xyz_output_matches_oracle(pvol, orc):
     pv.close()
 
 
-def test_single_call_shim_advances_the_callers_rng(pvol, orc):
-    """pvol_li: the per-sample entry behind VolumeIntegrator::Li, with the caller's live MT19937 state."""
-    s, p, rays, streams, c = load_li_case("pf_k50")
-    ph = load_photons("pf")
+@pytest.mark.parametrize("case,tag", [("pf_k50", "pf"), ("vh", "vh"), ("grid16", "grid16")])
+def test_single_call_shim_advances_the_callers_rng(pvol, orc, case, tag):
+    """pvol_li: the per-sample entry behind VolumeIntegrator::Li, with the caller's live MT19937 state -- two lights, ONE light
+    in a homogeneous medium (the BASELINE volumescene: round 2 answered PVOL_E_LIMIT there, the record plan's step bound was
+    only computed for several lights; found by tests/test_gpu_shim.py) and a VolumeGrid."""
+    s, p, rays, streams, c = load_li_case(case)
+    ph = load_photons(tag)
     pv = _ctx(pvol, s, p, ph)
     o = orc.Oracle(abi.SceneHolder(s), p)
     o.set_photons(*ph)

@@ -300,6 +300,31 @@ def test_surface_integrator_refuses_what_it_does_not_cover(torch_cuda):
         assert e.value.status == abi.PVOL_E_UNSUPPORTED
     finally:
         pv.close()
+    # an indirect photon map would make PhotonIntegrator::Li gather (photonmap.cpp:183-309: radiance and 144+ draws this path
+    # does not produce): refused whether the caller names it or the shooter kept one; and "take the preprocess store" without
+    # a preprocess that kept anything is an error, not an empty caustic map
+    s = load_scene("volumescene_h")
+    pv = pvol.PhotonVolume(abi.params_from_blob(s))
+    try:
+        pv.set_scene(abi.SceneHolder(s))
+        with pytest.raises(pvol.PvolError) as e:
+            pv.set_surface_integrator(50, 0.1, n_indirect=1000)
+        assert e.value.status == abi.PVOL_E_UNSUPPORTED
+        with pytest.raises(pvol.PvolError) as e:
+            pv.set_surface_integrator(50, 0.1, from_preprocess=True)
+        assert e.value.status == abi.PVOL_E_INVALID
+    finally:
+        pv.close()
+    pv = pvol.PhotonVolume(abi.params_from_blob(s, n_volume_photons=2000, n_caustic_photons=200, n_indirect_photons=200, keep_surface_photons=1))
+    try:
+        pv.set_scene(abi.SceneHolder(s))
+        pv.preprocess(16)
+        assert pv.shoot_stats()["stored_indirect"] > 0        # the shooter deposited indirect photons ...
+        with pytest.raises(pvol.PvolError) as e:
+            pv.set_surface_integrator(50, 0.1, from_preprocess=True)   # ... so the integrator described would gather
+        assert e.value.status == abi.PVOL_E_UNSUPPORTED
+    finally:
+        pv.close()
     # a heterogeneous medium: the surface term needs li_group_kernel's optical length, which the grid path does not report
     s, p, cam, film, smp, c = load_render_case("grid16")
     pv = pvol.PhotonVolume(p)

@@ -109,3 +109,30 @@ def test_what_is_not_covered_is_refused_by_name(tmp_path):
         with pytest.raises(ps.Unsupported) as e:
             ps.load(str(f))
         assert what in str(e.value)
+
+
+def test_omitted_parameters_take_the_reference_defaults(tmp_path):
+    """Every integrator parameter left out: CreatePhotonVolumeIntegrator (integrators/photonvolume.cpp:224-229: stepsize 1,
+    nused 250, maxdist 0.1), CreatePhotonShooter (core/photonshooter.cpp:529-548: volumephotons 0, stepsize 0.1,
+    maxphotondepth 5, causticphotons 20000, indirectphotons 10000, finalgather true), CreatePhotonMapSurfaceIntegrator
+    (integrators/photonmap.cpp:322-333: nused 50, maxspeculardepth 5, finalgather true, finalgathersamples 32, maxdist 0.1,
+    gatherangle 10) -- and the same values as pvol_default_params hands the C ABI."""
+    f = tmp_path / "d.pbrt"
+    f.write_text('Camera "perspective"\nSurfaceIntegrator "photonmap"\nVolumeIntegrator "photonvolume"\nWorldBegin\n'
+                 'Shape "trianglemesh" "integer indices" [0 1 2] "point P" [0 0 0  1 0 0  0 1 0]\nWorldEnd\n')
+    d = ps.load(str(f))
+    np.testing.assert_array_equal(d["params.f"], np.array([1.0, 0.1, 0.1], np.float32))
+    assert list(d["params.i"]) == [250, 0, 5, 20000, 10000, 1]
+    assert list(d["surf.params.i"]) == [50, 5, 1, 32]
+    np.testing.assert_array_equal(d["surf.params.f"], np.array([0.1, 10.0], np.float32))
+    p = abi.params_from_blob(d)
+    assert (p.n_used, p.n_volume_photons, p.max_photon_depth, p.n_caustic_photons, p.n_indirect_photons, p.final_gather) == (250, 0, 5, 20000, 10000, 1)
+    assert abs(p.step_size - 1.0) < 1e-9 and abs(p.max_dist - 0.1) < 1e-7 and abs(p.shooter_step_size - 0.1) < 1e-7
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SCENES), reason="the reference tree is not on this machine")
+def test_reference_scene_parameters_as_written():
+    """pinkfloyd.pbrt states the volume integrator's nused (500) and leaves the shooter's stepsize out (0.1)."""
+    d = ps.load(os.path.join(REF_SCENES, "pinkfloyd.pbrt"))
+    assert int(d["params.i"][0]) == 500 and int(d["surf.params.i"][0]) == 50
+    assert abs(float(d["params.f"][2]) - 0.1) < 1e-7

@@ -270,6 +270,53 @@ def partition_tasks(n_tiles, rank, world, weak):
     return np.arange(n_tiles) if weak else np.arange(rank, n_tiles, world)
 
 
+def emulate_ranks(args, torch, pv, pvol, abi, cam, film, smp, n_tiles, d_pixels, d_rgb, stream, n_photons):
+    """What ONE rank of an N-GPU strong-scaling run does, measured on the one GPU at hand: rank r's round-robin task list
+    rendered alone, per-phase device time from HIP events (pvol_get_phase_ms).  Projected N-GPU step = slowest emulated rank
+    + the film all-reduce (16 B per pixel; ring over xGMI at ~100 GB/s effective is < 1 ms at 720p and is ADDED as a constant
+    1.0 ms).  Efficiency = T(1) / (N * T(N)).  Not a measurement of N GPUs: no second card, no RCCL call."""
+    assert args.driver == "tile" and cam is not None
+    pv.enable_phase_timing(True)
+    sizes = [1] + [int(x) for x in args.emulate_ranks.split(",") if int(x) > 1]
+    out = {"emulation": True, "note": "per-rank task lists rendered one at a time on ONE GPU; projection, not a scaling measurement",
+           "workload": "volumescene (homogeneous) %dx%d, %d spp, %d photons, %d render tasks" % (args.xres, args.yres, args.spp, n_photons, n_tiles),
+           "reduce_ms_assumed": 1.0, "worlds": []}
+    t1 = None
+    for N in sizes:
+        ranks = sorted(set([0, N // 2, N - 1]))
+        rows = []
+        for r in ranks:
+            ids = partition_tasks(n_tiles, r, N, False).astype(np.uint32)
+            n_rays = pvol.render_sample_count(smp, ids)
+
+            def step():
+                d_pixels.zero_()
+                pv.render_tasks(cam, film, smp, ids, d_pixels.data_ptr(), None, stream)
+                pv.film_resolve(film, d_pixels.data_ptr(), d_rgb.data_ptr(), stream)
+            for _ in range(max(1, args.warmup)):
+                step()
+            torch.cuda.synchronize()
+            pv.phase_ms(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.steps * 1e3
+            ph = {k: v / args.steps for k, v in pv.phase_ms(reset=True).items()}
+            pv.check_errors()
+            rows.append({"rank": r, "tasks": int(len(ids)), "samples": int(n_rays), "step_ms": dt, "phases_ms": ph})
+        slow = max(x["step_ms"] for x in rows)
+        proj = slow + (out["reduce_ms_assumed"] if N > 1 else 0.0)
+        if N == 1:
+            t1 = proj
+        total = pvol.render_sample_count(smp, np.arange(n_tiles, dtype=np.uint32))
+        out["worlds"].append({"n_gpus": N, "ranks": rows, "projected_step_ms": proj, "projected_Msamples_per_s": total / proj / 1e3,
+                              "projected_efficiency": t1 / (N * proj)})
+    print(json.dumps(out))
+    pv.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,6 +343,10 @@ def main():
     ap.add_argument("--rehearse-one-gpu", action="store_true",
                     help="N > 1 ranks on ONE card (all on cuda:0, gloo for the collectives, the film staged through the host): "
                          "exercises the partition, the film reduce and the rank reductions where no multi-GPU node is at hand; not a measurement")
+    ap.add_argument("--emulate-ranks", default="",
+                    help="comma list of world sizes N (e.g. 2,4,8): on ONE GPU render the task list rank r of N would get (r = 0, N/2, N-1), "
+                         "time the step and its phases (tile pre-pass / march + gather / film), and print the projected N-GPU step time and "
+                         "strong-scaling efficiency.  An emulation on one card, not a scaling measurement")
     ap.add_argument("--save-image", default="", help="tile driver: write the resolved RGB film of the last step as .npy")
     args = ap.parse_args()
 
@@ -397,6 +448,9 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.emulate_ranks:
+        return emulate_ranks(args, torch, pv, pvol, abi, cam, film, smp, n_tiles, d_pixels, d_rgb, stream, n_photons)
 
     for _ in range(args.warmup):
         step()

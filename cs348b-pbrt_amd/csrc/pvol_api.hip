@@ -81,6 +81,7 @@ int pvol_create(const pvol_params *params, pvol_ctx **out) {
     { const char *ng = getenv("PVOL_NO_GROUP"); c->noGroup = ng && ng[0] == '1'; }
     { const char *nl = getenv("PVOL_NO_LITE"); c->noLite = nl && nl[0] == '1'; }
     { const char *gw = getenv("PVOL_GROUP_WAVES"); c->groupWavesPerCU = gw ? std::max(1, atoi(gw)) : 12; }
+    { const char *tw = getenv("PVOL_TILE_WAVES"); c->tileWaves = tw ? std::max(0, atoi(tw)) : 0; }
     // li_fixup_kernel / li_fixup_group_kernel waves per CU (C3, 8 spp frame: 16.3 s at 8, 13.9 s at 16)
     { const char *fw = getenv("PVOL_FIX_WAVES"); c->fixWavesPerCU = fw ? std::max(1, atoi(fw)) : 16; }
     { hipDeviceProp_t prop; if (ok(hipGetDeviceProperties(&prop, params->device))) c->nCU = prop.multiProcessorCount; }
@@ -126,8 +127,17 @@ void pvol_destroy(pvol_ctx *c) {
     pvol_free_surface_stores(c);
     pvol_free_caustic_map(c);
     if (c->dTau) hipFree(c->dTau);
+    if (c->dSegRays) hipFree(c->dSegRays);
+    if (c->dSegInfo) hipFree(c->dSegInfo);
+    if (c->dSegOut) hipFree(c->dSegOut);
+    if (c->dSegRecords) hipFree(c->dSegRecords);
+    if (c->dSegCounter) hipFree(c->dSegCounter);
+    if (c->dSegStream) hipFree(c->dSegStream);
+    if (c->dSpecLink) hipFree(c->dSpecLink);
     for (auto &p : c->pending) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &p : c->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    for (auto &p : c->phaseMarks) hipEventDestroy(p.second);
+    for (auto &e : c->phasePool) hipEventDestroy(e);
     if (c->dDensity) hipFree(c->dDensity);
     if (c->dBvhNodes) hipFree(c->dBvhNodes);
     if (c->dBvhTris) hipFree(c->dBvhTris);
@@ -509,6 +519,7 @@ void pvol_free_caustic_map(pvol_ctx *c) {
     if (c->dCCellStart) hipFree(c->dCCellStart);
     c->dCPos4 = c->dCAlpha4 = c->dCWi4 = 0; c->dCCellStart = 0;
     memset(&c->hs.surf, 0, sizeof(c->hs.surf));
+    c->specOn = false;
 }
 
 // PhotonIntegrator::Li in front of the volume term (include/pvol.h).  The caustic map gets the volume map's cell layout
@@ -521,12 +532,24 @@ int pvol_set_surface_integrator(pvol_ctx *c, const pvol_surface_params *sp, cons
     if (!sp) {
         hipDeviceSynchronize();
         pvol_free_caustic_map(c);
+        c->specOn = false;
         return pvol_push_scene(c);
     }
     if (sp->n_used < 1 || !(sp->max_dist > 0.f) || sp->max_specular_depth < 0) return PVOL_E_INVALID;
-    // the matte subset: a specular BSDF would need the recursion of SpecularReflect / SpecularTransmit (core/integrator.cpp:177-262)
-    for (size_t i = 0; i < c->triMatHost.size(); ++i)
-        if (c->hsh.mats[c->triMatHost[i]].kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
+    // matte and glass: a specular BSDF brings the recursion of SpecularReflect / SpecularTransmit (core/integrator.cpp:177-262,
+    // pvol_spec_dev.h), walked for "maxspeculardepth" up to SPEC_MAX_DEPTH (the reference's default)
+    bool anySpecular = false;
+    for (size_t i = 0; i < c->triMatHost.size(); ++i) {
+        const int kind = c->hsh.mats[c->triMatHost[i]].kind;
+        if (kind == PVOL_MATERIAL_GLASS) anySpecular = true;
+        else if (kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
+    }
+    for (int i = 0; i < c->hs.nSpheres; ++i) {
+        const int kind = c->hsh.mats[c->hs.spheres[i].mat].kind;
+        if (kind == PVOL_MATERIAL_GLASS) anySpecular = true;
+        else if (kind != PVOL_MATERIAL_MATTE) return PVOL_E_UNSUPPORTED;
+    }
+    if (anySpecular && sp->max_specular_depth > SPEC_MAX_DEPTH) return PVOL_E_UNSUPPORTED;
     // an indirect map makes PhotonIntegrator::Li gather: the final gather, or LPhoton(indirectMap) with 144 more rho draws
     // (photonmap.cpp:183-309).  None of that radiance and none of those draws exist here yet, so such an integrator is
     // refused by name rather than rendered wrong -- whether the map is the caller's (n_indirect_photons) or the store of
@@ -563,6 +586,7 @@ int pvol_set_surface_integrator(pvol_ctx *c, const pvol_surface_params *sp, cons
     pvol_free_caustic_map(c);
     DevSurface &sf = c->hs.surf;
     sf.enabled = 1; sf.nLookup = sp->n_used; sf.maxSpecularDepth = sp->max_specular_depth; sf.nCausticPaths = (int32_t)nPaths;
+    c->specOn = anySpecular && sp->max_specular_depth > 1;
     sf.maxDistSq = sp->max_dist * sp->max_dist;   // photonmap.cpp:345-346
     sf.nPhotons = 0;
     if (n) {
@@ -666,11 +690,95 @@ static bool harvest_events(pvol_ctx *c, bool wait) {
     return true;
 }
 
+// Phase timing (off by default: two events per kernel group otherwise).  A mark is an event on the launch stream.
+void pvol_phase_mark(pvol_ctx *c, hipStream_t stream, int id) {
+    if (!c->phaseOn) return;
+    std::lock_guard<std::mutex> g(c->mu);
+    hipEvent_t e;
+    if (!c->phasePool.empty()) { e = c->phasePool.back(); c->phasePool.pop_back(); }
+    else if (!ok(hipEventCreate(&e))) return;
+    hipEventRecord(e, stream);
+    c->phaseMarks.push_back(std::make_pair(id, e));
+}
+
+// Waves per render task of the COUNT-mode tile pre-pass.  A task is a serial chain (one MT19937 stream); with many tasks per CU
+// the chip is kept busy by running them side by side (one wave each), with few -- one rank's share of a multi-GPU frame -- the
+// draw count of every pixel is spread over several waves instead (tile_mw_kernel).  PVOL_TILE_WAVES overrides.
+static int tile_waves_per_task(const pvol_ctx *c, uint32_t nTasks) {
+    if (c->tileWaves > 0) return c->tileWaves;
+    const double perCU = (double)nTasks / (double)std::max(1, c->nCU);
+    return perCU >= 12.0 ? 1 : perCU >= 3.0 ? 4 : 16;
+}
+
+// ---- specular recursion (pvol_spec_dev.h): the pool of segment rays of one batch (COUNT mode) or one slice (FUSED mode)
+static int spec_pool_prepare(pvol_ctx *c, size_t cap, size_t recStride, hipStream_t stream) {
+    if (cap > c->segCap) {
+        hipStreamSynchronize(stream);
+        if (c->dSegRays) hipFree(c->dSegRays);
+        if (c->dSegInfo) hipFree(c->dSegInfo);
+        if (c->dSegOut) hipFree(c->dSegOut);
+        c->dSegRays = 0; c->dSegInfo = 0; c->dSegOut = 0; c->segCap = 0;
+        if (!ok(hipMalloc(&c->dSegRays, sizeof(pvol_ray) * cap)) || !ok(hipMalloc(&c->dSegInfo, sizeof(SegInfo) * cap)) ||
+            !ok(hipMalloc(&c->dSegOut, sizeof(float) * 60 * cap))) return PVOL_E_NO_MEMORY;
+        c->segCap = cap;
+    }
+    if (recStride * cap > c->segRecBytes) {
+        hipStreamSynchronize(stream);
+        if (c->dSegRecords) hipFree(c->dSegRecords);
+        c->dSegRecords = 0; c->segRecBytes = 0;
+        if (!ok(hipMalloc(&c->dSegRecords, recStride * cap))) return PVOL_E_NO_MEMORY;
+        c->segRecBytes = recStride * cap;
+    }
+    if (!c->dSegCounter && !ok(hipMalloc(&c->dSegCounter, 16))) return PVOL_E_NO_MEMORY;
+    if (!c->dSegStream && !ok(hipMalloc(&c->dSegStream, sizeof(pvol_stream)))) return PVOL_E_NO_MEMORY;
+    memset(&c->hSegStream, 0, sizeof(pvol_stream));
+    c->hSegStream.n_rays = (uint32_t)cap;
+    if (!ok(hipMemsetAsync(c->dSegCounter, 0, 16, stream)) || !ok(hipMemcpyAsync(c->dSegStream, &c->hSegStream, sizeof(pvol_stream), hipMemcpyHostToDevice, stream)) ||
+        !ok(pvol_launch_spec_fill(c->dSegRays, (uint32_t)cap, stream)) || !ok(hipMemsetAsync(c->dSegOut, 0, sizeof(float) * 60 * cap, stream)))
+        return PVOL_E_NO_DEVICE;
+    return PVOL_OK;
+}
+static size_t spec_pool_cap(size_t raysInFlight) {   // segments of one batch / slice: twice its camera samples, 64 k .. 16 M (the link holds 25 bits)
+    size_t cap = std::max<size_t>(65536, 2 * raysInFlight);
+    if (const char *ev = getenv("PVOL_SPEC_POOL")) { long long v = atoll(ev); if (v > 0) cap = (size_t)v; }
+    return std::min<size_t>(cap, (size_t)1 << 24);
+}
+static void spec_fill_tile(const pvol_ctx *c, TileArgs *t, size_t cap) {
+    t->specOn = 1; t->segRays = c->dSegRays; t->segInfo = c->dSegInfo; t->segCounter = c->dSegCounter; t->segCap = (uint32_t)cap;
+    t->segRecords = c->dSegRecords;
+}
+// The segments' own volume Li() (spectral), the surface term at their matte hits, and the fold into the camera samples.
+// `replay`: the pool's records were written by the FUSED tile pre-pass (li_replay_kernel); else no drawn value matters (li_par_kernel).
+static int spec_finish(pvol_ctx *c, const LiArgs &a, size_t cap, bool replay, uint32_t nPrimary, float *primaryOut, float *surfOut, hipStream_t stream) {
+    LiArgs sa = a;
+    sa.rays = c->dSegRays; sa.nRays = (uint32_t)cap; sa.streams = c->dSegStream; sa.nStreams = 1; sa.outputKind = PVOL_OUT_SPECTRAL;
+    sa.out = c->dSegOut; sa.draws = 0; sa.initState = 0; sa.finalState = 0; sa.tauOut = 0; sa.defer = 0; sa.deferCount = 0; sa.deferCap = 0; sa.gated = 0;
+    sa.records = c->dSegRecords; sa.sliceM = (uint32_t)cap; sa.sliceK = 0; sa.state = 0;
+    const uint32_t nWaves = (uint32_t)std::min<unsigned long long>((cap + 63) / 64, (unsigned long long)c->nCU * 16ull);
+    if (!ok(hipMemsetAsync(c->dWords, 0, 4 * sizeof(uint32_t), stream))) return PVOL_E_NO_DEVICE;
+    hipError_t e = replay ? pvol_launch_li_replay(&sa, lds_bytes_par(c), c->hs.candCap, nWaves, stream)
+                          : pvol_launch_li_par(&sa, lds_bytes_par(c), c->hs.candCap, false, nWaves, stream);
+    if (!ok(e)) return PVOL_E_NO_DEVICE;
+    SurfArgs su;
+    memset(&su, 0, sizeof(su));
+    su.scene = c->ds; su.rays = c->dSegRays; su.nRays = (uint32_t)cap; su.out = c->dSegOut; su.tau = 0; su.surfOut = 0; su.counters = c->dCounters; su.link = 0; su.spectral = 1;
+    if (!ok(pvol_launch_surface(&su, (uint32_t)std::min<unsigned long long>((cap + 63) / 64, (unsigned long long)c->nCU * 24ull), stream))) return PVOL_E_NO_DEVICE;
+    SpecComposeArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.scene = c->ds; ca.link = c->dSpecLink; ca.info = c->dSegInfo; ca.segOut = c->dSegOut; ca.tau = a.tauOut; ca.out = primaryOut; ca.surfOut = surfOut;
+    ca.first = 0; ca.nRays = nPrimary;
+    return ok(pvol_launch_spec_compose(&ca, stream)) ? PVOL_OK : PVOL_E_NO_DEVICE;
+}
+
 // `tile` != 0: the rays do not exist yet -- the tile kernel (pvol_tile_dev.h) generates them stream by stream
 // (LD sampler + camera) in front of the march, and takes the place of the RESOLVE pre-pass where one is needed.
 int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_stream *dStreams, uint32_t nStreams, int outputKind,
                       float *dOut, uint32_t *dDraws, const uint32_t *dInit, uint32_t *dFinal, int transOnly, uint32_t maxRaysPerStream,
                       const TileArgs *tile, hipStream_t stream) {
+    TileArgs tloc;   // the tile driver's arguments, completed here where the batch is cut into slices (segment pool of the specular recursion)
+    if (tile) { tloc = *tile; tile = &tloc; }
+    const bool spec = tile && tloc.specOn;
+    size_t specCap = 0;
     LiArgs a;
     memset(&a, 0, sizeof(a));
     a.scene = c->ds; a.rays = dRays; a.streams = dStreams; a.nStreams = nStreams; a.nRays = nRays; a.outputKind = outputKind;
@@ -720,6 +828,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         size_t m = budget / (stride * (size_t)nStreams);
         // nused beyond the bucket plan hands every dense lookup of a slice to the exact pass: keep that list within 8 GB
         if (c->hs.nUsed > 100) m = std::min<size_t>(m, std::max<size_t>(64, (((size_t)8 << 30) / sizeof(DeferRec) / 64) / (size_t)nStreams));
+        if (spec) m = std::min<size_t>(m, std::max<size_t>(64, ((size_t)8 << 20) / (size_t)nStreams));   // keeps a slice's segment pool within its 16 M slots
         m = std::max<size_t>(64, std::min<size_t>(m, ((size_t)maxRays + 63) & ~(size_t)63));
         m &= ~(size_t)63;
         if (const char *ev = getenv("PVOL_SLICE_RAYS")) { long v = atol(ev); if (v >= 64) m = (size_t)v & ~(size_t)63; }   // testing: force many slices
@@ -741,9 +850,18 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
     if (par) hipMemsetAsync(c->dWords, 0, 3 * sizeof(uint32_t), stream);
     if (tile && (par || (!sliced && tileCount))) {   // sampler + camera pre-pass, outside the timed region of the march kernel
         a.sliceK = 0; a.sliceM = 0xffffffc0u; a.state = 0;
-        if (!ok(pvol_launch_tile(&a, tile, false, pvol_tile_lds_bytes(0, tile->spp, false, c->hs.nTris, c->hs.nLights > 0 && c->hs.lights[0].kind == PVOL_LIGHT_DISTANT), c->hs.candCap, stream))) return PVOL_E_NO_DEVICE;
+        if (spec) {
+            specCap = spec_pool_cap(nRays);
+            int rc = spec_pool_prepare(c, specCap, 0, stream);
+            if (rc != PVOL_OK) return rc;
+            spec_fill_tile(c, &tloc, specCap);
+        }
+        pvol_phase_mark(c, stream, PVOL_PHASE_TILE);
+        if (!ok(pvol_launch_tile(&a, tile, false, pvol_tile_lds_bytes(0, tile->spp, false, c->hs.nTris, c->hs.nLights > 0 && c->hs.lights[0].kind == PVOL_LIGHT_DISTANT), c->hs.candCap, stream,
+                                 tile_waves_per_task(c, nStreams)))) return PVOL_E_NO_DEVICE;
     }
     hipEventRecord(ev.first, stream);
+    pvol_phase_mark(c, stream, PVOL_PHASE_MARCH);
     if (par) {
         unsigned long long chunks = ((unsigned long long)nRays + 63ull) / 64ull;
         uint32_t nWaves = (uint32_t)std::min<unsigned long long>(chunks, (unsigned long long)c->nCU * 16ull);
@@ -774,9 +892,14 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
         if (ok(e)) {   // runs only if a ray raised needSeq (gate read on the device: no host sync here)
             a.gated = 1;
             e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
+            a.gated = 0;
         }
-    } else if (a.tauOut) {
-        return PVOL_E_UNSUPPORTED;
+        if (ok(e) && spec) {
+            int rc = spec_finish(c, a, specCap, false, nRays, dOut, c->specSurfOut, stream);
+            if (rc != PVOL_OK) return rc;
+        }
+    } else if (a.tauOut && (!sliced || c->hs.volKind != PVOL_VOLUME_HOMOGENEOUS)) {
+        return PVOL_E_UNSUPPORTED;   // the surface term needs li_group_kernel's optical length of a homogeneous medium
     } else if (sliced) {
         c->lastKernel = "li_replay_kernel";
         e = hipSuccess;
@@ -808,23 +931,42 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             a.fixGroup = (c->hs.nUsed > 100 && !getenv("PVOL_FIX_EXACT")) ? 1 : 0;   // GRP_PLAN_KMAX: see pvol_fixgrp_dev.h
             c->lastKernel = "li_group_kernel";
         }
+        if (a.tauOut && !groupForm) return PVOL_E_UNSUPPORTED;
+        if (spec && !(tile && !tileGridCount && a.liteResolve)) return PVOL_E_UNSUPPORTED;   // the FUSED pre-pass walks the segments (geo_ray + lite_ray)
+        if (spec) specCap = spec_pool_cap((size_t)sliceM * nStreams);
         if (tileGridCount) {   // sampler + camera + draw COUNT for the whole batch, once
             LiArgs t = a;
             t.sliceK = 0; t.sliceM = 0xffffffc0u; t.state = 0;
-            e = pvol_launch_tile(&t, tile, false, pvol_tile_lds_bytes(0, tile->spp, false, c->hs.nTris, c->hs.nLights > 0 && c->hs.lights[0].kind == PVOL_LIGHT_DISTANT), c->hs.candCap, stream);
+            pvol_phase_mark(c, stream, PVOL_PHASE_TILE);
+            e = pvol_launch_tile(&t, tile, false, pvol_tile_lds_bytes(0, tile->spp, false, c->hs.nTris, c->hs.nLights > 0 && c->hs.lights[0].kind == PVOL_LIGHT_DISTANT), c->hs.candCap, stream,
+                                 tile_waves_per_task(c, nStreams));
         }
         for (uint32_t k = 0; k < nSlices && ok(e); ++k) {
             a.sliceK = k;
             hipMemsetAsync(c->dWords, 0, 4 * sizeof(uint32_t), stream);
-            if (tile && !tileGridCount) e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true, c->hs.nTris, false), c->hs.candCap, stream);
+            if (spec) {
+                int rc = spec_pool_prepare(c, specCap, a.recStride, stream);
+                if (rc != PVOL_OK) return rc;
+                spec_fill_tile(c, &tloc, specCap);
+            }
+            if (tile && !tileGridCount) {
+                pvol_phase_mark(c, stream, PVOL_PHASE_TILE);
+                e = pvol_launch_tile(&a, tile, true, pvol_tile_lds_bytes(c->hs.maxSteps, tile->spp, true, c->hs.nTris, false), c->hs.candCap, stream, 1);
+            }
+            pvol_phase_mark(c, stream, PVOL_PHASE_MARCH);   // incl. the RNG-only resolve pass of a slice where there is one
             if (ok(e)) e = pvol_launch_li_slice(&a, 624 * 4 + (size_t)c->hs.maxSteps * 4, lds_bytes_par(c), c->hs.candCap, c->statsOn, nWaves, stream,
                                                 tile == 0 || tileGridCount, groupForm, pvol_group_lds_bytes(c->hs.candCap), gWaves, (uint32_t)(c->nCU * c->fixWavesPerCU));
+            if (ok(e) && spec) {   // this slice's segments: their Li() from the records the pre-pass left, then the fold into the slice's camera samples
+                int rc = spec_finish(c, a, specCap, true, nRays, dOut, c->specSurfOut, stream);
+                if (rc != PVOL_OK) return rc;
+            }
         }
     } else {
         c->lastKernel = "li_seq_kernel";
         e = pvol_launch_li_seq(&a, lds_bytes_seq(c), c->hs.candCap, c->statsOn, stream);
     }
     hipEventRecord(ev.second, stream);
+    pvol_phase_mark(c, stream, PVOL_PHASE_END);
     {
         std::lock_guard<std::mutex> g(c->mu);
         c->pending.push_back(ev);
@@ -972,6 +1114,28 @@ int pvol_get_stats(pvol_ctx *c, pvol_stats *out, int reset) {
 }
 
 const char *pvol_march_kernel_name(pvol_ctx *c) { return c ? c->lastKernel : ""; }
+
+int pvol_enable_phase_timing(pvol_ctx *c, int on) {
+    if (!c) return PVOL_E_INVALID;
+    c->phaseOn = on != 0;
+    return PVOL_OK;
+}
+
+int pvol_get_phase_ms(pvol_ctx *c, double *out6, int reset) {
+    if (!c || !out6) return PVOL_E_INVALID;
+    if (!ok(hipSetDevice(c->params.device)) || !ok(hipDeviceSynchronize())) return PVOL_E_NO_DEVICE;
+    std::lock_guard<std::mutex> g(c->mu);
+    for (size_t i = 0; i + 1 < c->phaseMarks.size(); ++i) {
+        const int id = c->phaseMarks[i].first;
+        float ms = 0.f;
+        if (id >= 0 && id < PVOL_N_PHASES && ok(hipEventElapsedTime(&ms, c->phaseMarks[i].second, c->phaseMarks[i + 1].second))) c->phaseMs[id] += ms;
+    }
+    for (size_t i = 0; i < c->phaseMarks.size(); ++i) c->phasePool.push_back(c->phaseMarks[i].second);
+    c->phaseMarks.clear();
+    for (int i = 0; i < PVOL_N_PHASES; ++i) out6[i] = c->phaseMs[i];
+    if (reset) for (int i = 0; i < PVOL_N_PHASES; ++i) c->phaseMs[i] = 0.0;
+    return PVOL_OK;
+}
 
 int pvol_kernel_time_ms(pvol_ctx *c, double *avgMs, uint64_t *launches, int reset) {
     if (!c || !avgMs) return PVOL_E_INVALID;

@@ -140,6 +140,39 @@ struct DevCounters {
 };
 
 // surface_kernel (pvol_surface_dev.h)
+// ---- specular recursion of the surface integrator (pvol_spec_dev.h)
+#define SPEC_MAX_DEPTH 5          // "maxspeculardepth" values up to this are walked (the reference's default); more is refused on the host
+#define SPEC_LINK_DONE 0x80000000u // the sample's segments have been folded in (their pool slots may be reused by the next slice)
+#define SPEC_LINK_COUNT_BITS 6    // specLink = (first segment << 6) | segment count; a tree has at most 2 + 4 + 8 + 16 = 30 segments
+
+struct SegInfo {                  // one per segment ray, 32 bytes
+    uint32_t sample;              // index of the camera sample's primary ray in the batch
+    uint32_t depthLobeMat;        // depth (8 bits) | lobe (8: 1 reflection, 2 transmission) | material of the PARENT hit (16)
+    float Fs, awz, g;             // f (.) |cos| / pdf = ((Fs K) / awz) g:  Fs = F or 1 - F, awz = |cos| in the BSDF frame, g = AbsDot(wi, n) / pdf
+    uint32_t pad[3];
+};
+
+struct SpecComposeArgs {
+    const DevScene *scene;
+    uint32_t *link;           // per primary ray of the range: (first segment << 6) | count, 0 = none; SPEC_LINK_DONE is set once composed
+    const SegInfo *info;
+    const float *segOut;      // 60 floats per segment: Lv[30] (volume term + T (.) matte surface term), T[30]
+    const float *tau;         // per primary ray: optical length of Li()'s last march step
+    float *out;               // per primary ray X, Y, Z, T.y: the specular surface term is ADDED to X, Y, Z
+    float *surfOut;           // optional: the surface integrator's Li as X, Y, Z (3 floats per ray)
+    uint32_t first, nRays;    // the range of primary rays
+};
+
+// BxDFType bits (core/reflection.h:107-121)
+#ifndef BSDF_ALL
+#define BSDF_REFLECTION 1
+#define BSDF_TRANSMISSION 2
+#define BSDF_DIFFUSE 4
+#define BSDF_GLOSSY 8
+#define BSDF_SPECULAR 16
+#define BSDF_ALL 31
+#endif
+
 struct SurfArgs {
     const DevScene *scene;
     const pvol_ray *rays;
@@ -148,6 +181,8 @@ struct SurfArgs {
     const float *tau;      // per ray: optical length of the last march step (T = exp(-sigma_t * tau))
     float *surfOut;        // optional: the surface integrator's Li as X, Y, Z (3 floats per ray)
     DevCounters *counters;
+    const uint32_t *link;  // optional: per ray the specular-recursion link (pvol_spec_dev.h); linked samples keep the surfOut the composition wrote
+    int32_t spectral;      // 1: `out` holds 60 floats per ray (Lv[30], T[30], the segments of the specular recursion): T (.) Ls is added to Lv
 };
 
 // Tile driver (pvol_tile_dev.h, pvol_tile.hip): what a SamplerRendererTask needs besides the scene.
@@ -161,6 +196,14 @@ struct TileArgs {
     const int4 *windows;           // per stream of the batch: x0, x1, y0, y1 (Sampler::ComputeSubWindow)
     pvol_ray *rays;                // out: camera rays, stream-major, pixel-major, sample-minor
     float *xy;                     // out: imageX, imageY per ray
+    // specular recursion of the surface integrator (pvol_spec_dev.h): the spawned rays of camera samples that meet glass
+    int32_t specOn;
+    pvol_ray *segRays;             // pool of segment rays, laid out in stream order per camera sample
+    SegInfo *segInfo;
+    uint32_t *specLink;            // per primary ray: (first segment << 6) | count, 0 = none
+    uint32_t *segCounter;          // pool allocation counter
+    uint32_t segCap;
+    unsigned char *segRecords;     // FUSED mode: per segment slot one record of recStride bytes
     uint32_t debugSkip;            // timing experiments only (PVOL_TILE_DEBUG): 1 skip the swaps, 2 skip the draw count, 4 skip advancing the stream
 };
 

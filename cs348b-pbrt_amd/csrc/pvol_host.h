@@ -52,15 +52,21 @@ extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve
 extern "C" size_t pvol_group_lds_bytes(int candCap);
 extern "C" hipError_t pvol_launch_li_group(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, uint32_t nFixWaves,
                                            int replay, hipStream_t stream);
+extern "C" hipError_t pvol_launch_spec_compose(const SpecComposeArgs *a, hipStream_t stream);
+extern "C" hipError_t pvol_launch_spec_fill(pvol_ray *rays, uint32_t n, hipStream_t stream);
+extern "C" hipError_t pvol_launch_li_replay(const LiArgs *args, size_t ldsReplay, int candCap, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_launch_surface(const SurfArgs *a, uint32_t nWaves, hipStream_t stream);
 extern "C" size_t pvol_tile_lds_bytes(int maxSteps, uint32_t spp, bool fused, int nTris, bool shadowRows);
-extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream);
+extern "C" hipError_t pvol_launch_tile(const LiArgs *args, const TileArgs *tile, bool fused, size_t ldsBytes, int candCap, hipStream_t stream, int wavesPerTask);
 extern "C" hipError_t pvol_launch_li_par(const LiArgs *args, size_t ldsBytes, int candCap, bool stats, uint32_t nWaves, hipStream_t stream);
 extern "C" hipError_t pvol_build_grid(const GridBuildArgs *args, float4 *pos4, float4 *alpha4, float4 *wi4,
                                       uint32_t *cellStart, uint32_t *subStart, hipStream_t stream);
 extern "C" hipError_t pvol_build_bvh(const float *dTri, const int32_t *dMat, const int32_t *dFlip, uint32_t n, float pad, float4 *tris,
                                      float4 *nodes, hipStream_t stream);
 extern "C" hipError_t pvol_grid_occupancy(const uint32_t *cellStart, uint32_t ncells, double *sumSquares, hipStream_t stream);
+
+#define PVOL_N_PHASES 6
+enum { PVOL_PHASE_END = -1, PVOL_PHASE_TILE = 0, PVOL_PHASE_RNG = 1, PVOL_PHASE_MARCH = 2, PVOL_PHASE_SURFACE = 3, PVOL_PHASE_FILM = 4, PVOL_PHASE_OTHER = 5 };
 
 struct pvol_ctx {
     pvol_params params;
@@ -97,6 +103,13 @@ struct pvol_ctx {
     double timeMs;
     uint64_t launches;
     std::mutex mu;       // event lists only
+    // phase timing of the render driver (pvol_enable_phase_timing): marks on the launch stream, a mark opens phase `id` and
+    // closes the one before it; PVOL_PHASE_END closes without opening
+    int tileWaves = 0;       // PVOL_TILE_WAVES: waves per render task of the COUNT-mode tile pre-pass (0 = by tasks per CU)
+    bool phaseOn = false;
+    std::vector<std::pair<int, hipEvent_t> > phaseMarks;
+    std::vector<hipEvent_t> phasePool;
+    double phaseMs[PVOL_N_PHASES] = {0, 0, 0, 0, 0, 0};
     // One batch at a time per context: the launches of a batch share dWords / dRecords / dState / dCounters and the
     // deferred-lookup list.  Host entry points hold it from upload to copy-back (VolumeIntegrator::Li is called from every
     // SamplerRendererTask thread at once, samplerrenderer.cpp:247); device entry points hold it while they enqueue.
@@ -121,6 +134,19 @@ struct pvol_ctx {
     float *dTau = 0;       // per sample of a render batch: optical length the surface term is attenuated over
     size_t tauBytes = 0;
     float *dTauNext = 0;   // set by the render driver around pvol_launch_batch when the surface integrator is on
+    // specular recursion of the surface integrator (pvol_spec_dev.h): segments of the camera samples that meet glass
+    bool specOn = false;            // the scene holds a specular material and the surface integrator is on
+    pvol_ray *dSegRays = 0;
+    SegInfo *dSegInfo = 0;
+    float *dSegOut = 0;             // 60 floats per segment
+    unsigned char *dSegRecords = 0; // per-step records of the segments (scenes where drawn values matter)
+    uint32_t *dSegCounter = 0;
+    pvol_stream *dSegStream = 0;    // the pool seen as one stream of a ray batch
+    pvol_stream hSegStream;
+    size_t segCap = 0, segRecBytes = 0;
+    uint32_t *dSpecLink = 0;        // per primary ray of a render batch
+    size_t specLinkBytes = 0;
+    float *specSurfOut = 0;         // set by the render driver around pvol_launch_batch: where the composition reports the surface term
     double prepSeconds[2] = {0.0, 0.0};   // last pvol_preprocess: shooting (all rounds + merges), search-structure build
     // tile driver work buffers (grown on demand, pvol_tile.hip)
     void *dTile[6] = {0, 0, 0, 0, 0, 0};
@@ -134,6 +160,7 @@ extern "C" int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nR
                       const TileArgs *tile, hipStream_t stream);
 
 extern "C" {
+void pvol_phase_mark(pvol_ctx *c, hipStream_t stream, int id);
 // finish a photon map whose raw arrays (dRawP/dRawWi/dRawAlpha, n photons) are already on the device
 int pvol_finish_map(pvol_ctx *c, uint32_t n, const float *hostPositions);
 void pvol_free_photons(pvol_ctx *c);

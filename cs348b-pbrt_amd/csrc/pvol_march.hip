@@ -1426,6 +1426,16 @@ extern "C" hipError_t pvol_launch_li_slice(const LiArgs *args, size_t ldsResolve
     return hipGetLastError();
 }
 
+// li_replay_kernel on its own (the segment pool of the specular recursion: records written by the tile pre-pass, one wave per ray)
+extern "C" hipError_t pvol_launch_li_replay(const LiArgs *args, size_t ldsReplay, int candCap, uint32_t nWaves, hipStream_t stream) {
+    LiArgs a = *args;
+    a.gated = 0;
+    if (candCap <= 4 * LANES) hipLaunchKernelGGL((li_replay_kernel<false, 4>), dim3(nWaves), dim3(LANES), ldsReplay, stream, a);
+    else hipLaunchKernelGGL((li_replay_kernel<false, 12>), dim3(nWaves), dim3(LANES), ldsReplay, stream, a);
+    return hipGetLastError();
+}
+
 #include "pvol_group_dev.h"
 #include "pvol_surface_dev.h"
+#include "pvol_spec_dev.h"
 #include "pvol_tile_dev.h"

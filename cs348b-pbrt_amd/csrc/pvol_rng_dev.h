@@ -15,41 +15,79 @@ __device__ __forceinline__ uint32_t mt_twist(uint32_t a, uint32_t b) {
     uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
     return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
-// core/rng.cpp:80-92, 64 words per step.  Every kernel that owns an MT19937 state runs ONE wave per workgroup, and
-// the LDS operations of a wave execute in program order: within a step all lanes read before any lane writes (one
-// load instruction, then one store instruction), and a later step's reads see the earlier steps' writes -- exactly the
-// "old" and "new" words of the serial loop, without barriers (they cost ~4x in this latency-bound routine).
-__device__ void mt_regenerate(uint32_t *mt, int lane) {
-    for (int base = 0; base < MT_N - MT_M; base += LANES) {
-        int kk = base + lane;
-        if (kk < MT_N - MT_M) {
-            uint32_t v = mt[kk + MT_M] ^ mt_twist(mt[kk], mt[kk + 1]);
-            mt[kk] = v;
-        }
+// core/rng.cpp:80-92 by ONE wave, 64 words per instruction.  The serial loop's word kk needs the OLD words kk, kk+1 and -- for
+// kk < 227 -- the old word kk+397, else the NEW word kk-227.  The LDS operations of a wave execute in program order, so no
+// workgroup barrier is needed (they cost ~4x in this latency-bound routine) -- but the COMPILER must not move a load above a
+// store of another lane that feeds it: to the compiler every thread's own addresses are distinct, so after unrolling it may hoist
+// "mt[kk-227]" of a late step above the early step's store that (through another lane) produces that word.  (Round 3 found this:
+// the same source gave a correct schedule inside tile_kernel and a wrong one inside tile_mw_kernel.)  Hence four groups of steps
+// whose inputs are all complete before the group starts -- A: words 0..226 (old words only), B: 227..418 (new 0..191),
+// C: 419..610 (new 192..383), D: 611..623 (new 384..396, and new word 0 for the last) -- every group loads everything into
+// registers, then stores, with compiler barriers in between (no instruction, no wait: the hardware order does the rest).
+// WG1: the workgroup IS the wave that owns the state (every march kernel, the shooter, the one-wave tile kernel): __syncthreads.
+// !WG1: the owning wave is one of several in its workgroup (the multi-wave tile pre-pass) and must not touch the workgroup
+// barrier on its own: the same release / acquire fences as __syncthreads() without the s_barrier -- the LDS operations of
+// ONE wave execute in program order, so its own later reads see its earlier writes once the fence has drained the queue.
+template <bool WG1> __device__ __forceinline__ void rng_sync() {
+    if (WG1) __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    for (int base = MT_N - MT_M; base < MT_N - 1; base += LANES) {
-        int kk = base + lane;
-        if (kk < MT_N - 1) {
-            uint32_t v = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1]);
-            mt[kk] = v;
-        }
-    }
-    if (lane == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_twist(mt[MT_N - 1], mt[0]);
-    __syncthreads();
 }
-__device__ void mt_seed(uint32_t *mt, uint32_t seed, int lane) {  // core/rng.cpp:43-55
+#define PVOL_COMPILER_BARRIER() asm volatile("" ::: "memory")
+template <bool WG1 = true> __device__ void mt_regenerate(uint32_t *mt, int lane) {
+    uint32_t v[4];
+    // A: words 0 .. 226
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = LANES * j + lane;
+        if (kk < MT_N - MT_M) v[j] = mt[kk + MT_M] ^ mt_twist(mt[kk], mt[kk + 1]);
+    }
+    PVOL_COMPILER_BARRIER();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int kk = LANES * j + lane;
+        if (kk < MT_N - MT_M) mt[kk] = v[j];
+    }
+    PVOL_COMPILER_BARRIER();
+    // B: words 227 .. 418, C: words 419 .. 610
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int base = (MT_N - MT_M) + 3 * LANES * g;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int kk = base + LANES * j + lane;
+            v[j] = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1]);
+        }
+        PVOL_COMPILER_BARRIER();
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mt[base + LANES * j + lane] = v[j];
+        PVOL_COMPILER_BARRIER();
+    }
+    // D: words 611 .. 623 (the last one wraps to the new word 0)
+    {
+        const int kk = (MT_N - MT_M) + 6 * LANES + lane;
+        if (kk < MT_N) v[0] = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1 < MT_N ? kk + 1 : 0]);
+        PVOL_COMPILER_BARRIER();
+        if (kk < MT_N) mt[kk] = v[0];
+    }
+    rng_sync<WG1>();
+}
+template <bool WG1 = true> __device__ void mt_seed(uint32_t *mt, uint32_t seed, int lane) {  // core/rng.cpp:43-55
     uint32_t x = seed;
     if (lane == 0) mt[0] = x;
     for (int i = 1; i < MT_N; ++i) {
         x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
         if (lane == (i & 63)) mt[i] = x;
     }
-    __syncthreads();
+    rng_sync<WG1>();
 }
-template <bool SEQ> __device__ __forceinline__ uint32_t rng_uint(Rng &r, int lane) {
+template <bool SEQ, bool WG1 = true> __device__ __forceinline__ uint32_t rng_uint(Rng &r, int lane) {
     ++r.draws;
     if (!SEQ) return 0u;
-    if (r.mti >= MT_N) { mt_regenerate(r.mt, lane); r.mti = 0; }
+    if (r.mti >= MT_N) { mt_regenerate<WG1>(r.mt, lane); r.mti = 0; }
     uint32_t y = r.mt[r.mti++];
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
@@ -60,11 +98,11 @@ template <bool SEQ> __device__ __forceinline__ uint32_t rng_uint(Rng &r, int lan
 template <bool SEQ> __device__ __forceinline__ float rng_float(Rng &r, int lane) {
     return (rng_uint<SEQ>(r, lane) & 0xffffff) / float(1 << 24);   // core/rng.cpp:59-65
 }
-template <bool SEQ> __device__ __forceinline__ void rng_skip(Rng &r, unsigned long long n, int lane) {
+template <bool SEQ, bool WG1 = true> __device__ __forceinline__ void rng_skip(Rng &r, unsigned long long n, int lane) {
     r.draws += n;
     if (!SEQ) return;
     while (n > 0) {
-        if (r.mti >= MT_N) { mt_regenerate(r.mt, lane); r.mti = 0; }
+        if (r.mti >= MT_N) { mt_regenerate<WG1>(r.mt, lane); r.mti = 0; }
         unsigned long long avail = (unsigned long long)(MT_N - r.mti);
         unsigned long long take = n < avail ? n : avail;
         r.mti += (int)take;
@@ -74,12 +112,12 @@ template <bool SEQ> __device__ __forceinline__ void rng_skip(Rng &r, unsigned lo
 
 
 // draw j of the next `cnt` (<= 64) draws lands in lane j; the stream advances by cnt
-__device__ __forceinline__ uint32_t rng_bulk(Rng &r, int cnt, int lane) {
+template <bool WG1 = true> __device__ __forceinline__ uint32_t rng_bulk(Rng &r, int cnt, int lane) {
     uint32_t out = 0u;
     int done = 0;
     r.draws += (unsigned long long)cnt;
     while (done < cnt) {
-        if (r.mti >= MT_N) { mt_regenerate(r.mt, lane); r.mti = 0; }
+        if (r.mti >= MT_N) { mt_regenerate<WG1>(r.mt, lane); r.mti = 0; }
         const int take = min(cnt - done, MT_N - r.mti);
         if (lane >= done && lane < done + take) {
             uint32_t y = r.mt[r.mti + lane - done];

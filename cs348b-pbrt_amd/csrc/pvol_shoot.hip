@@ -28,12 +28,6 @@
 #define SH_STATE_WORDS 640   // per task in global memory: mt[624], mti, totalPaths, pad
 
 // BxDFType bits, core/reflection.h:107-121
-#define BSDF_REFLECTION 1
-#define BSDF_TRANSMISSION 2
-#define BSDF_DIFFUSE 4
-#define BSDF_GLOSSY 8
-#define BSDF_SPECULAR 16
-#define BSDF_ALL 31
 
 struct ShootArgs {
     const DevScene *scene;

@@ -17,6 +17,7 @@ struct SurfHit {
     float t;
     float rayEps;   // Intersection::rayEpsilon: 1e-3 t for a triangle (trianglemesh.cpp:205), 5e-4 t for a sphere (sphere.cpp:155)
     V3 p, nn;
+    V3 dpdu;        // the BSDF's frame starts from it (core/reflection.cpp:619-627)
 };
 // Scene::Intersect for one lane: closest hit, the later triangle on equal t (as the linear scans of this library and its oracle),
 // DifferentialGeometry normal as shapes/trianglemesh.cpp:163-181 + core/diffgeom.cpp:46-54 build it
@@ -57,6 +58,7 @@ __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit 
             h->t = mt;
             h->rayEps = 5e-4f * mt;
             sphere_dg(S.spheres[si], ph, &h->p, &dpduW, &h->nn);
+            h->dpdu = dpduW;
             return true;
         }
         if (best < 0) return false;
@@ -71,6 +73,7 @@ __device__ bool surf_closest(const DevScene &S, V3 o, V3 d, float mint, SurfHit 
     h->rayEps = 1e-3f * mt;
     h->p = o + d * mt;
     h->nn = normalize(cross(dpdu, dpdv));
+    h->dpdu = dpdu;
     if (flip) h->nn = h->nn * -1.f;
     return true;
 }
@@ -112,15 +115,15 @@ __device__ __forceinline__ SurfLight surf_light(const DevScene &S, int ln, V3 p,
     return r;
 }
 
-// RandomUInt calls of PhotonIntegrator::Li for a camera ray that hit triangle h (in front of the sample's volume Li())
-__device__ uint32_t surf_count_draws(const DevScene &S, const SurfHit &h, V3 d, unsigned blackMask) {
+// RandomUInt calls of PhotonIntegrator::Li for a ray of depth `depth` that hit h on a MATTE surface (in front of that ray's volume Li())
+__device__ uint32_t surf_count_draws(const DevScene &S, const SurfHit &h, V3 d, unsigned blackMask, int depth = 0) {
     const DevMaterial &m = S.shootScene->mats[h.mat];
     const bool lambert = m.kind == PVOL_MATERIAL_MATTE && m.nBxdf > 0;   // MatteMaterial::GetBSDF adds the Lambertian only for a non-black Kd
     const V3 wo = -d;
     uint32_t n = 0;
     for (int ln = 0; ln < S.nLights; ++ln) n += surf_light(S, ln, h.p, h.rayEps, h.nn, wo, lambert, blackMask).take ? 1u : 0u;
     if (S.surf.nPhotons > 0u && lambert) n += 144u;     // LPhoton(causticMap): two BSDF::rho(wo, rng)
-    if (0 + 1 < S.surf.maxSpecularDepth) n += 6u;       // SpecularReflect + SpecularTransmit: BSDFSample(rng) each
+    if (depth + 1 < S.surf.maxSpecularDepth) n += 6u;   // SpecularReflect + SpecularTransmit: BSDFSample(rng) each
     return n;
 }
 
@@ -150,8 +153,9 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
         const pvol_ray pr = A.rays[have ? ri : 0];
         const V3 o = v3(pr.o[0], pr.o[1], pr.o[2]), d = v3(pr.d[0], pr.d[1], pr.d[2]);
         SurfHit h;
-        h.tri = 0; h.mat = 0; h.t = 0.f; h.rayEps = 0.f; h.p = h.nn = v3(0.f, 0.f, 0.f);
-        const bool hit = have && surf_closest(S, o, d, pr.mint, &h);   // the ray's maxt is this very t (the tile pre-pass clipped it)
+        h.tri = 0; h.mat = 0; h.t = 0.f; h.rayEps = 0.f; h.p = h.nn = h.dpdu = v3(0.f, 0.f, 0.f);
+        // (the ray's maxt is this very t: the tile pre-pass clipped it; an unused slot of the segment pool has maxt < mint)
+        const bool hit = have && pr.maxt >= pr.mint && surf_closest(S, o, d, pr.mint, &h);
         float Ls[32];
 #pragma unroll
         for (int b = 0; b < 32; ++b) Ls[b] = 0.f;
@@ -281,7 +285,11 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
             }
         }
         // ---- compose: sample = T * Lsurface + Lvi
-        if (hit) {
+        if (hit && A.spectral) {   // a segment of the specular recursion: its T is in the record, the sum stays spectral
+            float *op = A.out + ri * 60;
+#pragma unroll
+            for (int b = 0; b < 30; ++b) op[b] += op[30 + b] * Ls[b];
+        } else if (hit) {
             const float kT = -1.442695041f * A.tau[ri];
             float x = 0.f, y = 0.f, z = 0.f, sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
             const float scale = float(700 - 400) / float(106.856895f * 30);
             float *op = A.out + ri * 4;
             op[0] += x * scale; op[1] += y * scale; op[2] += z * scale;
-            if (A.surfOut) { A.surfOut[3 * ri] = sx * scale; A.surfOut[3 * ri + 1] = sy * scale; A.surfOut[3 * ri + 2] = sz * scale; }
-        } else if (have && A.surfOut) {
+            if (A.surfOut && !(A.link && A.link[ri])) { A.surfOut[3 * ri] = sx * scale; A.surfOut[3 * ri + 1] = sy * scale; A.surfOut[3 * ri + 2] = sz * scale; }
+        } else if (have && A.surfOut && !A.spectral) {
             A.surfOut[3 * ri] = 0.f; A.surfOut[3 * ri + 1] = 0.f; A.surfOut[3 * ri + 2] = 0.f;
         }
     }

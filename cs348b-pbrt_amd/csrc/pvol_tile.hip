@@ -275,6 +275,21 @@ extern "C" int pvol_render_tasks_device(pvol_ctx *c, const pvol_camera *camera, 
         if (!ok(hipStreamSynchronize(stream))) return PVOL_E_NO_DEVICE;   // hs / win are host temporaries
         T.windows = dWin; T.rays = dRays; T.xy = dXY;
         const bool surfOn = c->hs.surf.enabled != 0;
+        const bool specOn = surfOn && c->specOn;
+        T.specOn = 0; T.specLink = 0;
+        if (specOn && nRays) {   // one link word per camera sample: which segments of the specular recursion belong to it
+            const size_t want = 4 * nRays;
+            if (want > c->specLinkBytes) {
+                hipStreamSynchronize(stream);
+                if (c->dSpecLink) hipFree(c->dSpecLink);
+                c->dSpecLink = 0; c->specLinkBytes = 0;
+                if (!ok(hipMalloc(&c->dSpecLink, want))) return PVOL_E_NO_MEMORY;
+                c->specLinkBytes = want;
+            }
+            T.specOn = 1; T.specLink = c->dSpecLink;
+            if (!ok(hipMemsetAsync(c->dSpecLink, 0, want, stream))) return PVOL_E_NO_DEVICE;
+            c->specSurfOut = debug && debug->d_surf_xyz ? debug->d_surf_xyz + 3 * doneRays : 0;
+        }
         if (surfOn && nRays) {
             const size_t want = 4 * nRays;
             if (want > c->tauBytes) {
@@ -292,14 +307,19 @@ extern "C" int pvol_render_tasks_device(pvol_ctx *c, const pvol_camera *camera, 
             if (rc != PVOL_OK) return rc;
             if (surfOn) {   // Ls of PhotonIntegrator::Li, composed as T * Ls + Lvi (samplerrenderer.cpp:95-97)
                 SurfArgs sa;
+                memset(&sa, 0, sizeof(sa));
+                sa.link = specOn ? c->dSpecLink : 0;
                 sa.scene = c->ds; sa.rays = dRays; sa.nRays = (uint32_t)nRays; sa.out = dOut; sa.tau = c->dTau;
                 sa.surfOut = debug ? debug->d_surf_xyz ? debug->d_surf_xyz + 3 * doneRays : 0 : 0;
                 sa.counters = c->dCounters;
                 const unsigned long long groups = (nRays + 63) / 64;
+                pvol_phase_mark(c, stream, PVOL_PHASE_SURFACE);
                 if (!ok(pvol_launch_surface(&sa, (uint32_t)std::min<unsigned long long>(groups, (unsigned long long)c->nCU * 24ull), stream)))
                     return PVOL_E_NO_DEVICE;
             }
+            pvol_phase_mark(c, stream, PVOL_PHASE_FILM);
             rc = film_add(c, film, dXY, dOut, 4, nRays, 1, dPixels, stream);
+            pvol_phase_mark(c, stream, PVOL_PHASE_END);
             if (rc != PVOL_OK) return rc;
         }
         if (debug) {

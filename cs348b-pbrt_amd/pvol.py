@@ -77,6 +77,8 @@ def lib():
                                                C.c_void_p, C.POINTER(abi.RenderDebug), C.c_void_p]
         L.pvol_film_add_samples_device.argtypes = [C.c_void_p, C.POINTER(abi.Film), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.pvol_film_resolve_device.argtypes = [C.c_void_p, C.POINTER(abi.Film), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pvol_enable_phase_timing.argtypes = [C.c_void_p, C.c_int]
+        L.pvol_get_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         _lib = L
     return _lib
 
@@ -88,7 +90,7 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
            "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_get_accel_info", "pvol_surface_photon_count",
            "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons",
-           "pvol_set_surface_integrator"]
+           "pvol_set_surface_integrator", "pvol_enable_phase_timing", "pvol_get_phase_ms"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -172,6 +174,15 @@ class PhotonVolume:
     def check_errors(self):
         """Raises PvolError(PVOL_E_LIMIT) if a batch enqueued through a device entry point hit a kernel limit."""
         _check(lib().pvol_check_errors(self._h), "pvol_check_errors")
+
+    def enable_phase_timing(self, on=True):
+        _check(lib().pvol_enable_phase_timing(self._h, int(bool(on))), "pvol_enable_phase_timing")
+
+    def phase_ms(self, reset=False):
+        """Device milliseconds per phase of render_tasks since the last reset: tile pre-pass, march + gather, surface, film."""
+        v = (C.c_double * 6)()
+        _check(lib().pvol_get_phase_ms(self._h, v, int(bool(reset))), "pvol_get_phase_ms")
+        return {"tile_prepass": v[0], "march_gather": v[2], "surface": v[3], "film_add": v[4]}
 
     def shoot_stats(self):
         v = (C.c_uint64 * 12)()

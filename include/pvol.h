@@ -380,6 +380,14 @@ int pvol_kernel_time_ms(pvol_ctx *ctx, double *avg_ms, uint64_t *launches, int r
  * "li_replay_kernel", "li_seq_kernel"; "" before the first batch): the kernel the time above belongs to. */
 const char *pvol_march_kernel_name(pvol_ctx *ctx);
 
+/* Per-phase device time of pvol_render_tasks_device, HIP events on the launch stream (off by default).  out[6], milliseconds
+ * summed since the last reset: [0] tile pre-pass (LDSampler + camera + Scene::Intersect clip + draw count: tile_kernel),
+ * [1] unused, [2] march + gather (li_group_kernel and its hand-over passes, or the slice loop incl. its RNG pass),
+ * [3] surface integrator, [4] ImageFilm::AddSample, [5] unused.  What one rank of a multi-GPU render spends where
+ * (bench.py --emulate-rank). */
+int pvol_enable_phase_timing(pvol_ctx *ctx, int on);
+int pvol_get_phase_ms(pvol_ctx *ctx, double *out6, int reset);
+
 /* GaussianFilter::Evaluate tabulated as ImageFilm's constructor does (filters/gaussian.h:44-58,
  * film/image.cpp:57-68). */
 void pvol_gaussian_filter_table(float xwidth, float ywidth, float alpha, float *table256);

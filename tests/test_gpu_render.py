@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import RENDER_CASES, RENDER_SURF_CASES, abi, load_photons, load_render_case, load_scene
+from conftest import RENDER_CASES, RENDER_SPECULAR_CASES, RENDER_SURF_CASES, abi, load_photons, load_render_case, load_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -288,16 +288,107 @@ def test_surface_integrator_matches_reference_capture(torch_cuda, name):
         pv.close()
 
 
+@pytest.mark.parametrize("name", list(RENDER_SPECULAR_CASES))
+def test_specular_recursion_matches_reference_capture(torch_cuda, name):
+    """Camera samples that meet the glass prism (pinkfloyd) / the glass ball (sphereroom): SpecularReflect + SpecularTransmit
+    (core/integrator.cpp:177-262) on the device -- the tree of spawned rays traced in the tile pre-pass, every spawned ray's
+    surface draws and its own volume Li() walked in the stream's order (two lights: the FUSED pre-pass), the segments' radiance
+    folded back through f |cos| / pdf and the transmittances.  Against the reference's own records: draws in front of every
+    camera sample's volume Li() and the stream ends exactly; surface radiance, T * Ls + Lvi and the film within 1e-4."""
+    from conftest import GOLD, blob
+    pvol = _pvol()
+    s, p, cam, film, smp, c = load_render_case(name)
+    tag = RENDER_SPECULAR_CASES[name][1]
+    cb = blob.load(os.path.join(GOLD, "caustic_%s.bin" % tag))
+    pv = pvol.PhotonVolume(p)
+    try:
+        pv.set_scene(abi.SceneHolder(s))
+        pv.upload_photons(*load_photons(tag))
+        pv.set_surface_integrator(int(c["surf.params.i"][0]), float(c["surf.params.f"][0]), 5, bool(c["surf.params.i"][1]),
+                                  (cb["p"].reshape(-1, 3), cb["wo"].reshape(-1, 3), cb["alpha"].reshape(-1, 30)), int(cb["n_paths"][0]))
+        n = len(c["samples.time"])
+        r = _render_surface(torch_cuda, pv, cam, film, smp, c["tasks"], n)
+        np.testing.assert_array_equal(r["xy"].ravel(), c["samples.image"])
+        np.testing.assert_array_equal(r["rays"]["maxt"], c["rays.t"][1::2])
+        assert (c["surf.draws"] > 151).sum() > 20                                      # samples through the glass: nested Li() draws
+        np.testing.assert_array_equal(r["rays"]["rng_skip"], c["rays.skip"])          # sampler + the whole tree of the surface integrator
+        np.testing.assert_array_equal(r["streams"]["end_draw"], c["task.end_draw"])
+        ref_s = c["surf.xyz"].reshape(-1, 3)
+        err = _rel_l2(r["surf_xyz"], ref_s)
+        assert err.max() <= 1e-4, "surface Li per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        ref = c["xyzT"].reshape(-1, 4)
+        err = _rel_l2(r["xyzT"][:, :3], ref[:, :3])
+        assert err.max() <= 1e-4, "T * Ls + Lvi per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        refpix = c["film.pixels"].reshape(film.y_resolution, film.x_resolution, 4)
+        np.testing.assert_allclose(r["pixels"], refpix, rtol=1e-4, atol=1e-5 * np.abs(refpix).max())
+    finally:
+        pv.close()
+
+
+@pytest.mark.parametrize("waves", ["1", "4"])
+def test_specular_recursion_one_light_matches_oracle(torch_cuda, orc, waves):
+    """The COUNT form of the pre-pass (one light: no drawn value reaches a result, the tree's draws are counted, one camera sample
+    per lane) on pinkfloyd without its point light, glass with a reflective lobe as well (a real tree, not a chain), against
+    the oracle -- which the reference's captures pin on the two-light scenes.  Also with the multi-wave pre-pass."""
+    from conftest import GOLD, blob
+    pvol = _pvol()
+    s, p, cam, film, smp, c = load_render_case("pf_surf")
+    s = dict(s)
+    for k in ("lights.kind", "lights.pos", "lights.dir", "lights.l2w", "lights.w2l", "lights.intensity", "lights.cos"):   # keep the spot light
+        per = len(s[k]) // 2
+        s[k] = s[k][:per].copy()
+    kr = s["mats.kr"].reshape(-1, 30).copy()
+    kr[s["mats.kind"] == abi.MATERIAL_GLASS] = 0.25
+    s["mats.kr"] = kr.ravel()
+    cb = blob.load(os.path.join(GOLD, "caustic_pf.bin"))
+    caustic = (cb["p"].reshape(-1, 3), cb["wo"].reshape(-1, 3), cb["alpha"].reshape(-1, 30))
+    ph = load_photons("pf")
+    p.n_used = 50
+    holder = abi.SceneHolder(s)
+    o = orc.Oracle(holder, p)
+    o.set_photons(*ph)
+    o.set_surface_integrator(50, 0.15, False, caustic, int(cb["n_paths"][0]))
+    ro = orc.render_tasks(o, cam, film, smp, c["tasks"])
+    assert not ro["unsupported_hits"]
+    old = os.environ.get("PVOL_TILE_WAVES")
+    os.environ["PVOL_TILE_WAVES"] = waves
+    try:
+        pv = pvol.PhotonVolume(p)
+    finally:
+        if old is None:
+            os.environ.pop("PVOL_TILE_WAVES", None)
+        else:
+            os.environ["PVOL_TILE_WAVES"] = old
+    try:
+        pv.set_scene(holder)
+        pv.upload_photons(*ph)
+        pv.set_surface_integrator(50, 0.15, 5, False, caustic, int(cb["n_paths"][0]))
+        n = ro["n_samples"]
+        r = _render_surface(torch_cuda, pv, cam, film, smp, c["tasks"], n)
+        assert pv.march_kernel_name() == "li_group_kernel"
+        np.testing.assert_array_equal(r["rays"]["rng_skip"], ro["rays"]["rng_skip"])
+        np.testing.assert_array_equal(r["streams"]["end_draw"], ro["end_draws"])
+        tree = ro["rays"]["rng_skip"] > 400
+        assert tree.sum() > 50
+        err = _rel_l2(r["surf_xyz"], ro["surf_xyz"].reshape(-1, 3))
+        assert err.max() <= 1e-4, "surface Li per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+        err = _rel_l2(r["xyzT"][:, :3], ro["xyzT"].reshape(-1, 4)[:, :3])
+        assert err.max() <= 1e-4, "T * Ls + Lvi per-sample rel L2 %.3g at %d" % (err.max(), err.argmax())
+    finally:
+        pv.close()
+
+
 def test_surface_integrator_refuses_what_it_does_not_cover(torch_cuda):
     pvol = _pvol()
-    # glass triangles: the recursion of SpecularReflect / SpecularTransmit is not implemented
+    # glass triangles: the recursion of SpecularReflect / SpecularTransmit is walked up to maxspeculardepth 5 (the default)
     s = load_scene("pinkfloyd")
     pv = pvol.PhotonVolume(abi.params_from_blob(s))
     try:
         pv.set_scene(abi.SceneHolder(s))
         with pytest.raises(pvol.PvolError) as e:
-            pv.set_surface_integrator(50, 0.1)
+            pv.set_surface_integrator(50, 0.1, max_specular_depth=6)
         assert e.value.status == abi.PVOL_E_UNSUPPORTED
+        pv.set_surface_integrator(50, 0.1, max_specular_depth=5)
     finally:
         pv.close()
     # an indirect photon map would make PhotonIntegrator::Li gather (photonmap.cpp:183-309: radiance and 144+ draws this path

@@ -267,7 +267,10 @@ def spawn_ranks(n):
 def partition_tasks(n_tiles, rank, world, weak):
     """north_star: the frame's render tasks (pixel tiles) are partitioned over the ranks, round-robin so every rank's share is
     spread over the frame; --weak gives every rank a whole frame of its own instead."""
-    return np.arange(n_tiles) if weak else np.arange(rank, n_tiles, world)
+    if weak:
+        return np.arange(n_tiles)
+    pvol = importlib.import_module("cs348b-pbrt_amd.pvol")   # the library's own partition (pvol_partition_tasks): what the C++ binding uses
+    return pvol.partition_tasks(int(n_tiles), int(rank), int(world)).astype(np.int64)
 
 
 def emulate_ranks(args, torch, pv, pvol, abi, cam, film, smp, n_tiles, d_pixels, d_rgb, stream, n_photons):

@@ -36,42 +36,70 @@ template <bool WG1> __device__ __forceinline__ void rng_sync() {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 }
+// Two forms, both independent of the compiler's schedule.  Which kernel gets which was decided by measurement: the tile pre-pass
+// is ~13 k instructions (more than the instruction cache holds) with the routine at a dozen call sites, and its time moved
+// between 181 and 373 ms (one-wave kernel, C2 frame) with the form, the inlining and the register allocation around it --
+// forced inlining and forced calls were both slower than leaving the choice to the compiler.
+//  * one-wave workgroups (march kernels, shooter, the one-wave tile pre-pass): the serial loop's own order, 64 words per step, every
+//    access of the state VOLATILE -- program order among volatile accesses is the one thing the compiler may not change.
+//    (One-wave tile pre-pass of the C2 frame: 226 ms; the unsafe round-2 form 181 ms; barrier forms 335 ms.)
+//  * the multi-wave tile pre-pass: two LDS round trips.  The OLD inputs of words 0..610 are loaded first; words 0..226 (A)
+//    follow from those alone, words 227..418 (B) need the NEW words 0..191, which THIS lane has just computed (kk - 227 =
+//    64 j + lane): registers, no load.  After A and B are stored, words 419..623 take the new words 192..396 (and the new word 0)
+//    -- other lanes' results -- through LDS.  Compiler barriers between "last old load | first store" and "stores of A, B |
+//    loads of the new words"; every load unconditional (clamped index).  (8 waves per task, 512 tasks: 98 ms; volatile loop 217.)
 #define PVOL_COMPILER_BARRIER() asm volatile("" ::: "memory")
-template <bool WG1 = true> __device__ void mt_regenerate(uint32_t *mt, int lane) {
-    uint32_t v[4];
-    // A: words 0 .. 226
+template <bool WG1 = true> __device__ void mt_regenerate(uint32_t *mt_, int lane) {
+    if (WG1) {
+        volatile uint32_t *mt = mt_;
+        for (int base = 0; base < MT_N - MT_M; base += LANES) {
+            const int kk = base + lane;
+            if (kk < MT_N - MT_M) { const uint32_t v = mt[kk + MT_M] ^ mt_twist(mt[kk], mt[kk + 1]); mt[kk] = v; }
+        }
+        for (int base = MT_N - MT_M; base < MT_N - 1; base += LANES) {
+            const int kk = base + lane;
+            if (kk < MT_N - 1) { const uint32_t v = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1]); mt[kk] = v; }
+        }
+        if (lane == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_twist(mt[MT_N - 1], mt[0]);
+    } else {
+        uint32_t *mt = mt_;
+        constexpr int NA = MT_N - MT_M;   // 227
+        uint32_t a0[4], a1[4], am[4], b0[3], b1[3], c0[3], c1[3];
+        const int k3 = min(3 * LANES + lane, NA - 1);   // group A, j = 3: words 192 .. 226 (lanes 0 .. 34)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kk = LANES * j + lane;
-        if (kk < MT_N - MT_M) v[j] = mt[kk + MT_M] ^ mt_twist(mt[kk], mt[kk + 1]);
-    }
-    PVOL_COMPILER_BARRIER();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int kk = LANES * j + lane;
-        if (kk < MT_N - MT_M) mt[kk] = v[j];
-    }
-    PVOL_COMPILER_BARRIER();
-    // B: words 227 .. 418, C: words 419 .. 610
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int base = (MT_N - MT_M) + 3 * LANES * g;
+        for (int j = 0; j < 4; ++j) {
+            const int kk = j < 3 ? LANES * j + lane : k3;
+            a0[j] = mt[kk]; a1[j] = mt[kk + 1]; am[j] = mt[kk + MT_M];
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int kk = base + LANES * j + lane;
-            v[j] = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1]);
+            const int kb = NA + LANES * j + lane, kc = NA + 3 * LANES + LANES * j + lane;
+            b0[j] = mt[kb]; b1[j] = mt[kb + 1];
+            c0[j] = mt[kc]; c1[j] = mt[kc + 1];
         }
+        const int kdRaw = NA + 6 * LANES + lane;   // 611 + lane, lanes 0 .. 12
+        const bool dOn = kdRaw < MT_N;
+        const int kd = min(kdRaw, MT_N - 1);
+        const uint32_t d0 = mt[kd], d1 = mt[min(kd + 1, MT_N - 1)];
+        PVOL_COMPILER_BARRIER();
+        uint32_t va[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = am[j] ^ mt_twist(a0[j], a1[j]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mt[LANES * j + lane] = va[j];
+        if (3 * LANES + lane < NA) mt[3 * LANES + lane] = va[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) mt[NA + LANES * j + lane] = va[j] ^ mt_twist(b0[j], b1[j]);   // new word kk - 227 is this lane's va[j]
+        PVOL_COMPILER_BARRIER();
+        uint32_t cn[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) cn[j] = mt[3 * LANES + LANES * j + lane];   // new words 192 .. 383
+        const uint32_t dn = mt[min(6 * LANES + lane, MT_N - 1)];                   // new words 384 .. 396 (lanes 0 .. 12)
+        const uint32_t n0 = mt[0];
         PVOL_COMPILER_BARRIER();
 #pragma unroll
-        for (int j = 0; j < 3; ++j) mt[base + LANES * j + lane] = v[j];
-        PVOL_COMPILER_BARRIER();
-    }
-    // D: words 611 .. 623 (the last one wraps to the new word 0)
-    {
-        const int kk = (MT_N - MT_M) + 6 * LANES + lane;
-        if (kk < MT_N) v[0] = mt[kk + (MT_M - MT_N)] ^ mt_twist(mt[kk], mt[kk + 1 < MT_N ? kk + 1 : 0]);
-        PVOL_COMPILER_BARRIER();
-        if (kk < MT_N) mt[kk] = v[0];
+        for (int j = 0; j < 3; ++j) mt[NA + 3 * LANES + LANES * j + lane] = cn[j] ^ mt_twist(c0[j], c1[j]);
+        if (dOn) mt[kd] = dn ^ mt_twist(d0, kdRaw + 1 < MT_N ? d1 : n0);
     }
     rng_sync<WG1>();
 }

@@ -50,6 +50,7 @@ struct ShootArgs {
     int keepSurface;
     unsigned long long *stats;  // paths, follow_calls, no_hit, march_steps, interactions, absorbed, split_children, overflow
     int init;                 // 1: seed RNG + Halton tables instead of shooting
+    int gridVolume;           // the medium is a VolumeGrid: the kernel takes GRID_KMAX x 64 more LDS words (march_grid)
 };
 
 // ------------------------------------------------------------------------------------------ spectra: lane b == bin b
@@ -400,6 +401,7 @@ struct PathCtx {
     float *fs, *fa;      // LDS frame stack: scalars, alphas
     float sigAl, sigSl, sigTl, cieYl;   // the lane's bin of sigma_a, sigma_s, their sum, the CIE Y weight (0 on the pad lanes)
     const float *cstT, *cstY;           // LDS: sigma_t[32], cieY[32] for the lane-per-step march
+    float *dbuf;                        // LDS, VolumeGrid only: GRID_KMAX x 64 densities (one column per lane) of the lane-per-step march
     bool causticDone, indirectDone, volumeDone;
     float *outPhotons;   // this task's local block buffer
     uint32_t cap;
@@ -453,6 +455,75 @@ __device__ bool march_analytic(PathCtx &C, V3 rayO, V3 dn, float t_i, float *t0i
     return false;
 }
 
+// The same march through a VolumeGrid (round 3; until then one Transmittance() at a time, every lane repeating the same density
+// fetches: C4's 2 M-photon map took 67 s).  Here too 64 iterations at a time, one per lane: lane j evaluates
+// Transmittance(ray(t_i .. t_j)) = Exp(-DensityRegion::tau) (core/volume.cpp:296-310) with ITS OWN drawn offset -- the values are
+// read ahead out of the MT19937 state without consuming them; only as many as the loop really made are skipped afterwards, and
+// a trip never reaches across a regeneration.  The decisions must be the serial loop's bit for bit, so the stepped sum is kept
+// per bin in the reference's order: the lane's densities D_k go to an LDS column first (the fetches are the expensive part,
+// now 64 wide), then tau_b = (sum_k sigma_t,b D_k) step for each bin, and y() in bin order.  A lane that needs more than
+// GRID_KMAX densities makes the trip fall back to the serial form (returns -1).
+#define GRID_KMAX 48
+__device__ int march_grid(PathCtx &C, V3 rayO, V3 dn, float t_i, float *t0io, float t1, float xi, int lane) {
+    const DevScene &S = *C.S;
+    const float stepSize = C.H->shooterStep;
+    const float step = 4.f * S.stepSize;   // PhotonVolumeIntegrator::Transmittance with sample == NULL (photonvolume.cpp:24-27)
+    float t0 = *t0io;
+    while (t0 < t1) {
+        if (C.rng.mti >= MT_N) { mt_regenerate(C.rng.mt, lane); C.rng.mti = 0; }
+        const int avail = MT_N - C.rng.mti;
+        float tj = t0;
+        int span = (int)fminf(63.f, (t1 - t0) / stepSize + 2.f);
+        span = min(span, avail - 1);
+        for (int i = 0; i < span; ++i) tj += (i < lane) ? stepSize : 0.f;
+        const bool active = (lane <= span) && tj < t1;
+        // the offset this iteration's Transmittance() would draw: draw number `lane` from here
+        uint32_t yv = C.rng.mt[C.rng.mti + min(lane, avail - 1)];
+        yv ^= (yv >> 11); yv ^= (yv << 7) & 0x9d2c5680u; yv ^= (yv << 15) & 0xefc60000u; yv ^= (yv >> 18);
+        const float offset = (yv & 0xffffff) / float(1 << 24);
+        // transmittance_bins' geometry for (mint, maxt) = (t_i, t_j)
+        const float length = len(dn);
+        RayD rn;
+        rn.o = rayO; rn.d = vdiv(dn, length); rn.mint = t_i * length; rn.maxt = tj * length;
+        float ta = 0.f, tb = 0.f;
+        const bool hit = active && length != 0.f && vol_intersect(S, rn, &ta, &tb);
+        int K = 0;
+        if (hit) {
+            float tt = ta + offset * step;
+            while (tt < tb && K < GRID_KMAX) {
+                C.dbuf[K * LANES + lane] = grid_density(S, xform_point(S.w2v, rn.o + rn.d * tt));
+                ++K;
+                tt += step;
+            }
+            if (tt < tb) K = GRID_KMAX + 1;   // does not fit: serial form for this trip
+        }
+        if (__ballot(K > GRID_KMAX)) { *t0io = t0; return -1; }
+        float yy = 0.f;
+        for (int b = 0; b < NBIN; ++b) {
+            const float sT = C.cstT[b];
+            float tau = 0.f;
+            for (int k = 0; k < K; ++k) tau += sT * C.dbuf[k * LANES + lane];
+            yy += C.cstY[b] * expf(-(tau * step));   // K == 0 (no overlap with the extent): exp(-0) = 1, as Transmittance returns 1
+        }
+        const float y = yy * float(700 - 400) / float(106.856895f * NBIN);
+        const uint64_t fire = __ballot(active && xi > y);
+        const int nAct = __popcll(__ballot(active));   // the active lanes are a prefix
+        if (fire) {
+            const int js = __ffsll((unsigned long long)fire) - 1;
+            C.march += (unsigned long long)(js + 1);
+            rng_skip<true>(C.rng, (unsigned long long)(js + 1), lane);
+            *t0io = lane_f(tj, js);
+            return 1;
+        }
+        C.march += (unsigned long long)nAct;
+        rng_skip<true>(C.rng, (unsigned long long)nAct, lane);
+        if (nAct <= span) { *t0io = t1; return 0; }   // some lane reached t1: the loop ended
+        t0 = lane_f(tj, span) + stepSize;
+    }
+    *t0io = t0;
+    return 0;
+}
+
 __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float alpha, float tag, int lane) {
     const DevScene &S = *C.S;
     const DevShootScene &H = *C.H;
@@ -487,12 +558,16 @@ __device__ void follow_photon(PathCtx &C, V3 rayO, V3 rayD, float rayMint, float
             if (S.volKind != PVOL_VOLUME_GRID) {
                 interaction = march_analytic(C, rayO, rn.d, t_i, &t0, t1, xi, lane);
             } else {
-                while (t0 < t1) {
+                int g = march_grid(C, rayO, rn.d, t_i, &t0, t1, xi, lane);
+                while (g < 0) {   // a segment with more density samples than the LDS columns hold: one serial step, then try again
+                    if (!(t0 < t1)) { g = 0; break; }
                     ++C.march;
                     const float tr = transmittance_bins(S, rayO, rn.d, t_i, t0, C.rng, C.sigTl, lane);
-                    if (xi > sp_y(tr, C.cieYl)) { interaction = true; break; }
+                    if (xi > sp_y(tr, C.cieYl)) { g = 1; break; }
                     t0 += H.shooterStep;
+                    g = march_grid(C, rayO, rn.d, t_i, &t0, t1, xi, lane);
                 }
+                interaction = g == 1;
             }
             bool toSurface = true;
             if (interaction) {
@@ -652,6 +727,7 @@ __global__ __launch_bounds__(LANES, WPE) void shoot_kernel(ShootArgs A) {
     uint32_t *perm = reinterpret_cast<uint32_t *>(cst + 64);         // 48 words
     float *fs = reinterpret_cast<float *>(perm + 48);                // SH_MAX_DEPTH x SH_FRAME_WORDS
     float *fa = fs + SH_MAX_DEPTH * SH_FRAME_WORDS;                  // SH_MAX_DEPTH x 32
+    float *dbuf = fa + SH_MAX_DEPTH * 32;                            // VolumeGrid only: GRID_KMAX x 64 (march_grid)
     uint32_t *haltonG = A.halton + (size_t)task * 48;
     Rng rng;
     rng.mt = mt;
@@ -700,6 +776,7 @@ __global__ __launch_bounds__(LANES, WPE) void shoot_kernel(ShootArgs A) {
     C.S = &S; C.H = &H; C.rng = rng; C.fs = fs; C.fa = fa;
     C.sigAl = sigAl; C.sigSl = sigSl; C.sigTl = sigAl + sigSl; C.cieYl = binLane ? S.cieY[lane] : 0.f;
     C.cstT = cst; C.cstY = cst + 32;
+    C.dbuf = dbuf;
     C.causticDone = fl & 1u; C.indirectDone = fl & 2u; C.volumeDone = fl & 4u;
     C.outPhotons = A.localPhotons + (size_t)task * A.cap * 36;
     C.cap = A.cap;
@@ -833,7 +910,8 @@ extern "C" hipError_t pvol_launch_merge_surface(const SurfMergeArgs *m, hipStrea
 extern "C" size_t pvol_shoot_state_words(void) { return SH_STATE_WORDS; }
 
 extern "C" hipError_t pvol_launch_shoot(const ShootArgs *a, hipStream_t stream) {
-    const size_t ldsBytes = MT_N * 4 + 64 * 4 + 48 * 4 + (size_t)SH_MAX_DEPTH * SH_FRAME_WORDS * 4 + (size_t)SH_MAX_DEPTH * 32 * 4;
+    const size_t ldsBytes = MT_N * 4 + 64 * 4 + 48 * 4 + (size_t)SH_MAX_DEPTH * SH_FRAME_WORDS * 4 + (size_t)SH_MAX_DEPTH * 32 * 4 +
+                            (a->gridVolume ? (size_t)GRID_KMAX * LANES * 4 : 0);
     // registers: the path state is ~240 wave-uniform values; 2 waves per SIMD hold them without spills, 4 spill ~160 of
     // them to scratch but hide more latency (PVOL_SHOOT_WPE picks; measured in profiles/)
     static const int wpe = [] { const char *e = getenv("PVOL_SHOOT_WPE"); const int v = e ? atoi(e) : 2; return (v == 4 || v == 3) ? v : 2; }();

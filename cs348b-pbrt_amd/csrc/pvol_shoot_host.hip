@@ -29,6 +29,7 @@ struct ShootArgs {
     int keepSurface;
     unsigned long long *stats;
     int init;
+    int gridVolume;           // the medium is a VolumeGrid: the kernel takes GRID_KMAX x 64 more LDS words (march_grid)
 };
 struct SurfMergeArgs {
     const float *localSurf; const uint32_t *localSurfKind; uint32_t capS;
@@ -141,6 +142,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     A.scene = c->ds; A.shoot = c->dsh; A.nTasks = T; A.stateIn = B.stateA; A.stateOut = B.stateA; A.halton = B.halton; A.flags = B.flags;
     A.localPhotons = B.localPhotons; A.localCounts = B.localCounts; A.cap = cap; A.stats = B.stats; A.init = 1;
     A.localSurf = B.localSurf; A.localSurfKind = B.localSurfKind; A.capS = capS; A.localRad = B.localRad; A.capR = capR; A.keepSurface = keep ? 1 : 0;
+    A.gridVolume = c->hs.volKind == PVOL_VOLUME_GRID ? 1 : 0;
     if (!ok(pvol_launch_shoot(&A, 0)) || !ok(hipDeviceSynchronize())) { B.release(false); return PVOL_E_NO_DEVICE; }
     A.init = 0;
     A.stateOut = B.stateB;

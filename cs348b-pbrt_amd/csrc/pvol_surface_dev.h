@@ -128,6 +128,110 @@ __device__ uint32_t surf_count_draws(const DevScene &S, const SurfHit &h, V3 d, 
 }
 
 
+__device__ __forceinline__ V3 lane_v3(V3 v, int l) { return v3(lane_f(v.x, l), lane_f(v.y, l), lane_f(v.z, l)); }
+// The caustic lookup of ONE hit point whose ball holds more photons than the LDS bucket (a caustic's focus): the whole wave streams
+// the photons of the ball's cell rows from global memory -- how many lie inside maxdist; when at least nused do, the nused-th
+// smallest distance^2 by bisection over the fp32 bit pattern (one pass per step, as the bucket form does over LDS); then the flux
+// sum over the members (ties at the nused-th distance in photon order).  Every lane returns the wave's sums in acc[0..29]:
+// Lr = sum kernel / (nPaths r^2) alpha over the members on the wo side (photonmap.cpp:62-108).
+__device__ __attribute__((noinline)) void caustic_stream(const DevScene &S, const GridView &cg, V3 P, V3 Nf, int k, int lane, float *acc) {
+    const float maxD2 = S.surf.maxDistSq;
+    const GridRows R = grid_rows<false>(cg, P, sqrtf(maxD2), 0);
+    // pass 0: count inside; pass 1..: bisection steps; each pass visits every photon of the rows once
+    uint32_t lo = 0u, hi = __float_as_uint(maxD2), kth = 0xffffffffu;
+    int nIn = 0, less = 0;
+    for (int pass = 0; pass < 40; ++pass) {
+        const bool counting = pass == 0;
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        int cnt = 0;
+        for (int r = 0; r < R.nrows; ++r) {
+            uint32_t start, rlen;
+            grid_row_range<false>(cg, R, r, P, maxD2, &start, &rlen);
+            for (uint32_t b = 0; b < rlen; b += LANES) {
+                const uint32_t i = b + (uint32_t)lane;
+                bool hitp = false;
+                if (i < rlen) {
+                    const float4 q = cg.pos4[start + i];
+                    const float dx = q.x - P.x, dy = q.y - P.y, dz = q.z - P.z;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    hitp = counting ? d2 < maxD2 : __float_as_uint(d2) <= mid;
+                }
+                cnt += __popcll(__ballot(hitp));
+            }
+        }
+        if (counting) { nIn = cnt; if (nIn < k) break; continue; }
+        if (cnt >= k) hi = mid; else lo = mid + 1u;
+        if (!(lo < hi)) { kth = lo; break; }
+    }
+    float r2 = maxD2;
+    int tieQuota = 0;
+    if (kth != 0xffffffffu) {
+        r2 = __uint_as_float(kth);
+        for (int r = 0; r < R.nrows; ++r) {
+            uint32_t start, rlen;
+            grid_row_range<false>(cg, R, r, P, maxD2, &start, &rlen);
+            for (uint32_t b = 0; b < rlen; b += LANES) {
+                const uint32_t i = b + (uint32_t)lane;
+                bool lt = false;
+                if (i < rlen) {
+                    const float4 q = cg.pos4[start + i];
+                    const float dx = q.x - P.x, dy = q.y - P.y, dz = q.z - P.z;
+                    lt = __float_as_uint(dx * dx + dy * dy + dz * dz) < kth;
+                }
+                less += __popcll(__ballot(lt));
+            }
+        }
+        tieQuota = k - less;
+    }
+    float a[32];
+#pragma unroll
+    for (int b = 0; b < 32; ++b) a[b] = 0.f;
+    const float norm = 1.f / ((float)S.surf.nCausticPaths * r2);
+    int tiesSeen = 0;
+    for (int r = 0; r < R.nrows; ++r) {
+        uint32_t start, rlen;
+        grid_row_range<false>(cg, R, r, P, maxD2, &start, &rlen);
+        for (uint32_t b = 0; b < rlen; b += LANES) {
+            const uint32_t i = b + (uint32_t)lane;
+            bool mem = false, tie = false;
+            float d2 = 0.f;
+            if (i < rlen) {
+                const float4 q = cg.pos4[start + i];
+                const float dx = q.x - P.x, dy = q.y - P.y, dz = q.z - P.z;
+                d2 = dx * dx + dy * dy + dz * dz;
+                if (kth == 0xffffffffu) mem = d2 < maxD2;
+                else { const uint32_t bits = __float_as_uint(d2); mem = bits < kth; tie = bits == kth; }
+            }
+            const unsigned long long tb = __ballot(tie);
+            if (tie) {
+                const int rank = tiesSeen + __popcll(tb & ((1ull << lane) - 1ull));
+                mem = rank < tieQuota;
+            }
+            tiesSeen += __popcll(tb);
+            if (mem) {
+                const f4 wi4 = S.surf.wi4[start + i];
+                if (Nf.x * wi4.x + Nf.y * wi4.y + Nf.z * wi4.z > 0.f) {
+                    const float sW = 1.f - d2 / r2;
+                    const float wgt = (3.f * 0.31830988618379067154f * sW * sW) * norm;
+                    const float4 *row = S.surf.alpha4 + (size_t)(start + i) * 8;
+#pragma unroll
+                    for (int qq = 0; qq < 8; ++qq) {
+                        const float4 rr = row[qq];
+                        a[4 * qq] = __builtin_fmaf(rr.x, wgt, a[4 * qq]); a[4 * qq + 1] = __builtin_fmaf(rr.y, wgt, a[4 * qq + 1]);
+                        a[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, a[4 * qq + 2]); a[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, a[4 * qq + 3]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 30; ++b) {
+        float v = a[b];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        acc[b] = v;
+    }
+}
+
 // One camera sample per lane, 64 consecutive samples (one pixel's, at >= 64 spp) per group: their hit points lie within a
 // pixel footprint, so the caustic lookups share one LDS bucket of the photons within maxdist + spread of the group's centre.
 __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
@@ -199,8 +303,10 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
             V3 c = v3(0.5f * (lx + hx), 0.5f * (ly + hy), 0.5f * (lz + hz));
             float rho = wave_max(waiting ? len(h.p - c) : 0.f);
             bool need = waiting;
+            int pivLane = 0;
             if (alone || rho > maxDist) {
                 const int piv = __ffsll((long long)pending) - 1;
+                pivLane = piv;
                 c = v3(lane_f(h.p.x, piv), lane_f(h.p.y, piv), lane_f(h.p.z, piv));
                 const float dPiv = len(h.p - c);
                 need = waiting && (alone ? dPiv == 0.f : dPiv <= maxDist);
@@ -213,8 +319,13 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
             if (Mb < 0 && !alone) { alone = true; continue; }   // retry with the first waiting sample on its own
             pending &= ~__ballot(need);
             alone = false;
-            if (Mb < 0) {   // more photons within maxdist of ONE point than the bucket holds: reported, never guessed
-                if (lane == 0) atomicAdd(&A.counters->nErrors, 1ull);
+            if (Mb < 0) {   // more photons within maxdist of ONE point than the bucket holds: streamed from the grid for that point
+                float sa[32];
+                caustic_stream(S, cg, c, dot(lane_v3(h.nn, pivLane), lane_v3(wo, pivLane)) < 0.f ? lane_v3(h.nn, pivLane) * -1.f : lane_v3(h.nn, pivLane), k, lane, sa);
+                if (need) {
+#pragma unroll
+                    for (int b = 0; b < 30; ++b) Ls[b] += sa[b] * mat.kd[b] * 0.31830988618379067154f;
+                }
             } else {
                 // pass A: how many photons lie inside maxdist (kdtree.h:180: dist2 < maxDistSquared), and -- when that is at least
                 // nused -- the nused-th smallest distance^2 by bisection over the fp32 bit pattern (the heap of PhotonProcess keeps

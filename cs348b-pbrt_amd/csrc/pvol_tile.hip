@@ -8,6 +8,9 @@
 #include <algorithm>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the library is bound at run time (pvol_render_frame_ranks)
+
 #include "pvol_host.h"
 #include "pvol_math.h"
 
@@ -332,4 +335,57 @@ extern "C" int pvol_render_tasks_device(pvol_ctx *c, const pvol_camera *camera, 
         b0 = b1;
     }
     return PVOL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU frame (north_star)
+// The frame's render tasks dealt round-robin to the ranks: rank r renders tasks r, r + n, r + 2n, ... so that every rank's share
+// is spread over the whole frame (SamplerRenderer::Render's task loop, renderers/samplerrenderer.cpp:206-221, cut n ways).
+extern "C" int pvol_partition_tasks(uint32_t nTasks, uint32_t rank, uint32_t nRanks, uint32_t *outIds, uint32_t capacity, uint32_t *nOut) {
+    if (!nRanks || rank >= nRanks || !nOut) return PVOL_E_INVALID;
+    const uint32_t n = rank < nTasks ? (nTasks - rank + nRanks - 1) / nRanks : 0;
+    *nOut = n;
+    if (!outIds) return PVOL_OK;
+    if (capacity < n) return PVOL_E_INVALID;
+    for (uint32_t i = 0; i < n; ++i) outIds[i] = rank + i * nRanks;
+    return PVOL_OK;
+}
+
+// RCCL is bound at run time: a process that already holds a copy (the application's own, or the one PyTorch ships) keeps using
+// that one, and a single-GPU user of this library never loads it.
+typedef ncclResult_t (*nccl_reduce_fn)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t);
+static nccl_reduce_fn bind_nccl_reduce() {
+    static nccl_reduce_fn fn = 0;
+    static bool tried = false;
+    if (tried) return fn;
+    tried = true;
+    if (void *sym = dlsym(RTLD_DEFAULT, "ncclReduce")) { fn = (nccl_reduce_fn)sym; return fn; }
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names)
+        if (void *h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))
+            if (void *sym = dlsym(h, "ncclReduce")) { fn = (nccl_reduce_fn)sym; break; }
+    return fn;
+}
+
+// One rank of an N-GPU frame: its share of the render tasks into its own full-frame film, ONE ncclReduce(sum) of the film to rank 0
+// (the Gaussian filter splats across tile borders, film/image.cpp:82-134, so tiles cannot simply be gathered), resolve on rank 0.
+// The photon map is replicated: every rank runs pvol_preprocess with the same seeds beforehand -- nothing else crosses GPUs.
+extern "C" int pvol_render_frame_ranks(pvol_ctx *c, const pvol_camera *camera, const pvol_film *film, const pvol_sampler *smp,
+                                       uint32_t rank, uint32_t nRanks, void *ncclComm, float *dPixels, float *dRgb, void *hipStream) {
+    if (!c || !smp || !film_ok(film) || !dPixels || !nRanks || rank >= nRanks) return PVOL_E_INVALID;
+    if (nRanks > 1 && !ncclComm) return PVOL_E_INVALID;
+    nccl_reduce_fn reduce = 0;
+    if (nRanks > 1 && !(reduce = bind_nccl_reduce())) return PVOL_E_NO_DEVICE;   // no RCCL in reach
+    if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
+    hipStream_t stream = (hipStream_t)hipStream;
+    uint32_t n = 0;
+    pvol_partition_tasks(smp->n_tasks, rank, nRanks, 0, 0, &n);
+    std::vector<uint32_t> ids(n);
+    pvol_partition_tasks(smp->n_tasks, rank, nRanks, ids.data(), n, &n);
+    const size_t nFloats = (size_t)film->x_resolution * film->y_resolution * 4;
+    if (!ok(hipMemsetAsync(dPixels, 0, nFloats * sizeof(float), stream))) return PVOL_E_NO_DEVICE;
+    int rc = pvol_render_tasks_device(c, camera, film, smp, ids.data(), n, dPixels, 0, hipStream);
+    if (rc != PVOL_OK) return rc;
+    if (nRanks > 1 && reduce(dPixels, dPixels, nFloats, ncclFloat, ncclSum, 0, (ncclComm_t)ncclComm, stream) != ncclSuccess) return PVOL_E_NO_DEVICE;
+    if (rank == 0 && dRgb) rc = pvol_film_resolve_device(c, film, dPixels, dRgb, hipStream);
+    return rc;
 }

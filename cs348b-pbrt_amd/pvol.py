@@ -77,6 +77,9 @@ def lib():
                                                C.c_void_p, C.POINTER(abi.RenderDebug), C.c_void_p]
         L.pvol_film_add_samples_device.argtypes = [C.c_void_p, C.POINTER(abi.Film), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p]
         L.pvol_film_resolve_device.argtypes = [C.c_void_p, C.POINTER(abi.Film), C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pvol_partition_tasks.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _u32p]
+        L.pvol_render_frame_ranks.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.Film), C.POINTER(abi.Sampler), C.c_uint32, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.pvol_enable_phase_timing.argtypes = [C.c_void_p, C.c_int]
         L.pvol_get_phase_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
         _lib = L
@@ -90,10 +93,20 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_gaussian_filter_table", "pvol_compute_sub_window", "pvol_render_sample_count", "pvol_render_tasks_device",
            "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_get_accel_info", "pvol_surface_photon_count",
            "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons",
-           "pvol_set_surface_integrator", "pvol_enable_phase_timing", "pvol_get_phase_ms"]
+           "pvol_set_surface_integrator", "pvol_enable_phase_timing", "pvol_get_phase_ms",
+           "pvol_partition_tasks", "pvol_render_frame_ranks"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
+
+
+def partition_tasks(n_tasks, rank, n_ranks):
+    """pvol_partition_tasks: the task numbers rank `rank` of `n_ranks` renders (pure host code: needs no GPU)."""
+    n = C.c_uint32()
+    _check(lib().pvol_partition_tasks(n_tasks, rank, n_ranks, None, 0, C.byref(n)), "pvol_partition_tasks")
+    ids = np.zeros(n.value, np.uint32)
+    _check(lib().pvol_partition_tasks(n_tasks, rank, n_ranks, ids.ctypes.data_as(_u32p), n.value, C.byref(n)), "pvol_partition_tasks")
+    return ids
 
 
 def _check(rc, where):
@@ -174,6 +187,11 @@ class PhotonVolume:
     def check_errors(self):
         """Raises PvolError(PVOL_E_LIMIT) if a batch enqueued through a device entry point hit a kernel limit."""
         _check(lib().pvol_check_errors(self._h), "pvol_check_errors")
+
+    def render_frame_ranks(self, cam, film, smp, rank, n_ranks, nccl_comm, d_pixels, d_rgb=0, hip_stream=0):
+        """One rank of an N-GPU frame behind the C ABI: partition, render, ncclReduce of the film, resolve on rank 0."""
+        _check(lib().pvol_render_frame_ranks(self._h, C.byref(cam), C.byref(film), C.byref(smp), rank, n_ranks, nccl_comm, d_pixels, d_rgb, hip_stream),
+               "pvol_render_frame_ranks")
 
     def enable_phase_timing(self, on=True):
         _check(lib().pvol_enable_phase_timing(self._h, int(bool(on))), "pvol_enable_phase_timing")

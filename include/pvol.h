@@ -421,6 +421,20 @@ int pvol_render_tasks_device(pvol_ctx *ctx, const pvol_camera *camera, const pvo
 int pvol_set_surface_integrator(pvol_ctx *ctx, const pvol_surface_params *sp, const float *p, const float *wo,
                                 const float *alpha, uint32_t n);
 
+/* ---- multi-GPU frame (north_star: pixel tiles partitioned over the GPUs of a node, one RCCL reduce of the film) ----
+ * Rank `rank` of `n_ranks` renders the tasks rank, rank + n_ranks, ... of SamplerRenderer::Render's task loop
+ * (renderers/samplerrenderer.cpp:206-221).  out_ids may be NULL to ask for the count only. */
+int pvol_partition_tasks(uint32_t n_tasks, uint32_t rank, uint32_t n_ranks, uint32_t *out_ids, uint32_t capacity, uint32_t *n_out);
+
+/* One rank's part of a frame, enqueued on hip_stream: d_pixels (x*y*4 floats, this rank's device) is zeroed, the rank's tasks are
+ * rendered into it (pvol_render_tasks_device), ONE ncclReduce(sum, root 0) over `nccl_comm` (an ncclComm_t of n_ranks ranks made by
+ * the caller with RCCL: ncclCommInitRank; ignored when n_ranks == 1) adds the ranks' films -- the Gaussian filter splats across tile
+ * borders (film/image.cpp:82-134), so the films are summed, not gathered -- and rank 0 resolves into d_rgb (x*y*3 floats; may be
+ * NULL on the other ranks).  The photon map is replicated: every rank calls pvol_preprocess with the same task count first.
+ * RCCL is bound at run time (the copy already in the process, else librccl.so.1): PVOL_E_NO_DEVICE if none is in reach. */
+int pvol_render_frame_ranks(pvol_ctx *ctx, const pvol_camera *camera, const pvol_film *film, const pvol_sampler *sampler,
+                            uint32_t rank, uint32_t n_ranks, void *nccl_comm, float *d_pixels, float *d_rgb, void *hip_stream);
+
 /* ImageFilm::AddSample (film/image.cpp:78-137) for n samples: d_image_xy 2 floats, d_xyz `xyz_stride`
  * floats per sample (X,Y,Z first). */
 int pvol_film_add_samples_device(pvol_ctx *ctx, const pvol_film *film, const float *d_image_xy,

@@ -144,6 +144,20 @@ public:
         return Exp(-scene->volumeRegion->tau(ray, step, offset));
     }
 
+    // One rank of a multi-GPU render (north_star: pixel tiles partitioned over the GPUs of one node, one RCCL reduce of the film):
+    // what a renderer calls on rank `rank` of `nRanks` INSTEAD of SamplerRenderer::Render's task loop, after every rank ran
+    // Preprocess (same seeds: identical photon maps, nothing to exchange).  `ncclComm` is the caller's ncclComm_t (ncclCommInitRank);
+    // dPixels / dRgb are buffers on this rank's device; rank 0 ends up with the resolved frame.
+    int RenderFrameRanks(const PerspectiveCamera *camera, const ImageFilm *film, const LDSampler *sampler, const Sample *origSample,
+                         int nTasks, int rank, int nRanks, void *ncclComm, float *dPixels, float *dRgb, void *hipStream) const {
+        pvol_camera cam;
+        pvol_film f;
+        pvol_sampler smp;
+        int rc = fillTileArgs(camera, film, sampler, origSample, nTasks, &cam, &f, &smp);
+        if (rc != PVOL_OK) return rc;
+        return pvol_render_frame_ranks(ctx, &cam, &f, &smp, (uint32_t)rank, (uint32_t)nRanks, ncclComm, dPixels, dRgb, hipStream);
+    }
+
     pvol_ctx *context() const { return ctx; }
     int TauSampleOffset() const { return tauSampleOffset; }
     int ScatterSampleOffset() const { return scatterSampleOffset; }
@@ -155,26 +169,12 @@ public:
     int RenderTasks(const PerspectiveCamera *camera, const ImageFilm *film, const LDSampler *sampler, const Sample *origSample,
                     int nTasks, float *d_pixels, float *d_rgb, void *hipStream, const std::vector<uint32_t> *taskList = NULL) const {
         pvol_camera cam;
-        memset(&cam, 0, sizeof(cam));
-        putMat(cam.raster_to_camera, camera->RasterToCamera.m);
-        putMat(cam.camera_to_world, camera->CameraToWorld.startTransform->m);   // static cameras only
-        cam.shutter_open = camera->shutterOpen; cam.shutter_close = camera->shutterClose;
-        cam.lens_radius = camera->lensRadius; cam.focal_distance = camera->focalDistance;
         pvol_film f;
-        memset(&f, 0, sizeof(f));
-        f.x_resolution = film->xResolution; f.y_resolution = film->yResolution;
-        f.filter_xwidth = film->filter->xWidth; f.filter_ywidth = film->filter->yWidth;
-        memcpy(f.filter_table, film->filterTable, sizeof(f.filter_table));
         pvol_sampler smp;
-        memset(&smp, 0, sizeof(smp));
-        film->GetSampleExtent(&smp.x_start, &smp.x_end, &smp.y_start, &smp.y_end);
-        smp.pixel_samples = sampler->samplesPerPixel;
-        smp.n_tasks = nTasks;
-        smp.n1d_count = origSample->n1D.size(); smp.n2d_count = origSample->n2D.size();
-        if (smp.n1d_count > PVOL_MAX_SAMPLE_ARRAYS || smp.n2d_count > PVOL_MAX_SAMPLE_ARRAYS) return PVOL_E_LIMIT;
-        for (uint32_t i = 0; i < smp.n1d_count; ++i) smp.n1d[i] = origSample->n1D[i];
-        for (uint32_t i = 0; i < smp.n2d_count; ++i) smp.n2d[i] = origSample->n2D[i];
-        smp.tau_index = tauSampleOffset; smp.scatter_index = scatterSampleOffset;
+        {
+            int rc0 = fillTileArgs(camera, film, sampler, origSample, nTasks, &cam, &f, &smp);
+            if (rc0 != PVOL_OK) return rc0;
+        }
         std::vector<uint32_t> tasks;   // all of them, or the caller's share (one rank of a multi-GPU render)
         if (taskList) tasks = *taskList;
         else for (int t = 0; t < nTasks; ++t) tasks.push_back(t);
@@ -184,6 +184,33 @@ public:
     }
 
 private:
+    // PerspectiveCamera / ImageFilm / LDSampler / Sample -> the PODs of include/pvol.h
+    int fillTileArgs(const PerspectiveCamera *camera, const ImageFilm *film, const LDSampler *sampler, const Sample *origSample, int nTasks,
+                     pvol_camera *pcam, pvol_film *pf, pvol_sampler *psmp) const {
+        pvol_camera &cam = *pcam;
+        pvol_film &f = *pf;
+        pvol_sampler &smp = *psmp;
+        memset(&cam, 0, sizeof(cam));
+        putMat(cam.raster_to_camera, camera->RasterToCamera.m);
+        putMat(cam.camera_to_world, camera->CameraToWorld.startTransform->m);   // static cameras only
+        cam.shutter_open = camera->shutterOpen; cam.shutter_close = camera->shutterClose;
+        cam.lens_radius = camera->lensRadius; cam.focal_distance = camera->focalDistance;
+        memset(&f, 0, sizeof(f));
+        f.x_resolution = film->xResolution; f.y_resolution = film->yResolution;
+        f.filter_xwidth = film->filter->xWidth; f.filter_ywidth = film->filter->yWidth;
+        memcpy(f.filter_table, film->filterTable, sizeof(f.filter_table));
+        memset(&smp, 0, sizeof(smp));
+        film->GetSampleExtent(&smp.x_start, &smp.x_end, &smp.y_start, &smp.y_end);
+        smp.pixel_samples = sampler->samplesPerPixel;
+        smp.n_tasks = nTasks;
+        smp.n1d_count = origSample->n1D.size(); smp.n2d_count = origSample->n2D.size();
+        if (smp.n1d_count > PVOL_MAX_SAMPLE_ARRAYS || smp.n2d_count > PVOL_MAX_SAMPLE_ARRAYS) return PVOL_E_LIMIT;
+        for (uint32_t i = 0; i < smp.n1d_count; ++i) smp.n1d[i] = origSample->n1D[i];
+        for (uint32_t i = 0; i < smp.n2d_count; ++i) smp.n2d[i] = origSample->n2D[i];
+        smp.tau_index = tauSampleOffset; smp.scatter_index = scatterSampleOffset;
+        return PVOL_OK;
+    }
+
     static void fillRay(const Ray &ray, pvol_ray *r) {
         memset(r, 0, sizeof(*r));
         r->o[0] = ray.o.x; r->o[1] = ray.o.y; r->o[2] = ray.o.z;

@@ -23,6 +23,7 @@ abi, blob = pkg.abi, pkg.blob
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+    config.addinivalue_line("markers", "slow: a CPU test of a minute or more (still part of -m 'not gpu')")
 
 
 @pytest.fixture(scope="session")

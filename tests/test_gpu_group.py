@@ -232,7 +232,8 @@ def _grid_scene(n):
     return s
 
 
-@pytest.mark.parametrize("case", ["grid128", "pinkfloyd_k500", "pinkfloyd_k500_exactpass", "pinkfloyd_k50"])
+@pytest.mark.parametrize("case", ["grid128", "pinkfloyd_k500", "pinkfloyd_k500_exactpass", "pinkfloyd_k50",
+                                  "pinkfloyd_k500_subgrid0", "pinkfloyd_k500_subgrid1", "vh_subgrid0", "vh_subgrid1"])
 def test_group_replay_form_matches_oracle(pvol, orc, case):
     """Scenes where drawn values reach the result run as RNG pre-pass + li_group_kernel's REPLAY form (+ the exact-lookup pass):
     C4's 128^3 VolumeGrid (trilinear density and stepped tau() per lane, recorded offsets), and pinkfloyd's two lights with
@@ -240,9 +241,17 @@ def test_group_replay_form_matches_oracle(pvol, orc, case):
     selection of the 500 nearest; `_exactpass`: to li_fixup_kernel, one wave per lookup) and with nused 50 (the bucket plan proper)."""
     import os
     old_env = os.environ.pop("PVOL_FIX_EXACT", None)
+    old_sub = os.environ.pop("PVOL_SUBGRID", None)
     if case == "pinkfloyd_k500_exactpass":
         os.environ["PVOL_FIX_EXACT"] = "1"
-    if case == "grid128":
+    # the second grid level (4 x 4 x 4 sub-cells, chosen by a data-dependent threshold when the map is built) forced off and on:
+    # results do not depend on it (`_subgridN`; the variable is read when the map is finished, i.e. inside preprocess)
+    if "_subgrid" in case:
+        os.environ["PVOL_SUBGRID"] = case[-1]
+    if case.startswith("vh_"):
+        s = load_scene("volumescene_h")
+        over, n_photons, n_tasks, res, spp, tasks = {}, 150000, 8192, (256, 256), 16, [40, 130, 200]
+    elif case == "grid128":
         s = _grid_scene(128)
         over, n_photons, n_tasks, res, spp, tasks = {}, 200000, 2048, (256, 256), 16, [40, 130, 200]
     elif case.startswith("pinkfloyd_k500"):
@@ -280,5 +289,8 @@ def test_group_replay_form_matches_oracle(pvol, orc, case):
     finally:
         pv.close()
         os.environ.pop("PVOL_FIX_EXACT", None)
+        os.environ.pop("PVOL_SUBGRID", None)
         if old_env is not None:
             os.environ["PVOL_FIX_EXACT"] = old_env
+        if old_sub is not None:
+            os.environ["PVOL_SUBGRID"] = old_sub

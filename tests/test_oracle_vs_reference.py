@@ -241,12 +241,26 @@ def test_shooter_work_counters_equal_the_compiled_reference(orc):
     assert st["follow_calls"] == 2516360
     assert st["march_steps"] == 44109004
     assert st["split_children"] == 1318800
-    # The other scene the survey measured (C1-h: volumescene, distant light, final gather on, 100 k photons) is NOT equal
-    # integer for integer: the oracle stores 100 005 photons from 43 233 280 paths (345 897 879 march steps) where the
-    # survey's parser-built scene gave 100 012 / 43.2 M / 345.8 M -- the same within 0.03 %, i.e. one decision differs
-    # somewhere in 43 M paths (the fixture scene is assembled by oracle/ref_capture.cpp through the reference's Create*()
-    # calls, not by core/api.cpp's transform stack, which cannot be linked).  97 s of single-thread work: not run here;
-    # the ratios are asserted on the committed 6 k map above.
+
+
+@pytest.mark.slow
+def test_shooter_on_volumescene_is_parity_unpinned_and_guarded(orc):
+    """PARITY UNPINNED.  The other scene the survey measured (C1-h: volumescene with the homogeneous medium, distant light, 5 000
+    caustic photons, final gather on, 100 000 volume photons, --ncores 1) does NOT reproduce integer for integer: the survey's
+    compiled reference stored 100 012 volume photons from "43.2 M" paths and "345.8 M" march steps (only the first
+    figure is exact), the oracle stores 100 005 from 43 233 280 paths and 345 897 879 march steps.  The cause is unknown: the
+    scene the oracle shoots equals the parser-built one bit for bit (tests/test_pbrt_scene.py), the reference's
+    PhotonShootingTask cannot be linked here to bisect (core/parallel.cpp needs <sys/sysctl.h>), and the same oracle code IS
+    integer-exact on pinkfloyd (spot + point light, prism) above -- what volumescene adds is the distant light's emission
+    (DistantLight::Sample_L(scene, ...), pinned record by record in ref_units_volumescene_h) and the radiance-photon deposits of
+    `finalgather true`.  Every C2 number therefore rests on a photon map whose generator is pinned on a different scene.
+    This test guards the oracle's own integers so that drift is caught (about 100 s of single-thread work)."""
+    s = load_scene("volumescene_h")
+    o = orc.Oracle(abi.SceneHolder(s), abi.params_from_blob(s, n_volume_photons=100000))
+    assert o.shoot(1, 1) == 0
+    st = o.shoot_stats()
+    assert (st["stored_volume"], st["paths"], st["march_steps"]) == (100005, 43233280, 345897879)
+    assert st["stored_volume"] != 100012          # the reference's count (SURVEY 6): not reproduced, cause unknown
 
 
 def test_oracle_surface_stores_are_what_it_counts(orc):

@@ -24,14 +24,16 @@ def main():
     ap.add_argument("--photons", type=int, default=1000000)
     ap.add_argument("--xres", type=int, default=1280)
     ap.add_argument("--yres", type=int, default=720)
+    ap.add_argument("--scene", default="volumescene_h", help="volumescene_h (the bench's C2) or pinkfloyd (C3: nused 500, two lights; camera rays unclipped)")
+    ap.add_argument("--shoot-tasks", type=int, default=16384)
     a = ap.parse_args()
     import torch
     pkg = importlib.import_module("cs348b-pbrt_amd")
     abi, blob = pkg.abi, pkg.blob
     os.makedirs(a.out, exist_ok=True)
-    scene = blob.load(os.path.join(bench.GOLD, "scene_volumescene_h.bin"))
+    scene = blob.load(os.path.join(bench.GOLD, "scene_%s.bin" % a.scene))
     holder = abi.SceneHolder(scene)
-    params = abi.params_from_blob(scene, n_volume_photons=a.photons)
+    params = abi.params_from_blob(scene, n_volume_photons=a.photons) if a.scene == "volumescene_h" else abi.params_from_blob(scene, n_volume_photons=a.photons, n_caustic_photons=0)
     with open(os.path.join(a.out, "scene.bin"), "wb") as f:
         f.write(bytes(holder.scene))
         f.write(bytes(holder.lights)[:C.sizeof(abi.Light) * holder.scene.n_lights])
@@ -46,7 +48,7 @@ def main():
         pvol = importlib.import_module("cs348b-pbrt_amd.pvol")
         pv = pvol.PhotonVolume(params)
         pv.set_scene(holder)
-        pv.preprocess(16384)
+        pv.preprocess(a.shoot_tasks)
         p, w, al = pv.download_photons()
         pv.close()
     except Exception as e:   # noqa: BLE001
@@ -56,9 +58,14 @@ def main():
         f.write(np.uint32(len(p)).tobytes())
         f.write(p.tobytes()); f.write(w.tobytes()); f.write(al.tobytes())
     x0s, x1s, y0s, y1s, n_tiles = bench.frame_tiles(a.xres, a.yres)
-    rays, counts = bench.build_rays(torch, torch.device("cpu"), scene, a.xres, a.yres, a.spp, (x0s, x1s, y0s, y1s), seed=1234)
-    st = abi.make_streams(np.arange(n_tiles, dtype=np.uint32), counts.astype(np.uint32))
-    r = rays.numpy()
+    if a.scene == "volumescene_h":
+        rays, counts = bench.build_rays(torch, torch.device("cpu"), scene, a.xres, a.yres, a.spp, (x0s, x1s, y0s, y1s), seed=1234)
+        st = abi.make_streams(np.arange(n_tiles, dtype=np.uint32), counts.astype(np.uint32))
+        r = rays.numpy()
+    else:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import measure_configs
+        r, st = measure_configs.rays_for(scene, a.xres, a.yres, a.spp, 7)
     with open(os.path.join(a.out, "rays.bin"), "wb") as f:
         f.write(np.uint32(len(r)).tobytes()); f.write(np.uint32(len(st)).tobytes())
         f.write(r.tobytes()); f.write(st.tobytes())

@@ -66,6 +66,45 @@ def grid_scene(scene, n):
     return scene
 
 
+def parity_leg(torch, pv, scene, params, xres, yres, spp, n_tiles, n_pick=16, spp_cap=16):
+    """In-run parity of a frame line: whole render tasks of THIS frame (same photon map -- downloaded from the device --,
+    same parameters, same task windows and seeds) through the oracle's SamplerRendererTask loop and through the device tile driver, at
+    min(spp, spp_cap) samples per pixel so that the oracle finishes in a minute.  Per-pixel relative L2 (the north_star's bar: 1e-4) and
+    the RNG stream end of every task (exact)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    spp_p = min(spp, spp_cap)
+    cam = abi.perspective_camera(float(scene["camera.fov"][0]), xres, yres, scene["camera.c2w"])
+    film = abi.make_film(xres, yres, pvol.gaussian_filter_table())
+    smp = abi.make_sampler(xres, yres, spp_p, n_tiles)
+    pick = np.unique(np.linspace(0, n_tiles - 1, n_pick).astype(np.uint32))
+    cores = max(1, min(os.cpu_count() or 1, 16))
+    o = orc.Oracle(abi.SceneHolder(scene), params)
+    o.set_photons(*pv.download_photons())
+    t0 = time.perf_counter()
+    ref = orc.render_tasks(o, cam, film, smp, pick, records=True, n_threads=cores)
+    t_cpu = time.perf_counter() - t0
+    n = len(ref["xyzT"])
+    dev = torch.device("cuda:0")
+    px = torch.zeros((yres, xres, 4), dtype=torch.float32, device=dev)
+    xyz = torch.zeros((max(n, 1), 4), dtype=torch.float32, device=dev)
+    streams = torch.zeros((len(pick), 32), dtype=torch.uint8, device=dev)
+    pv.render_tasks(cam, film, smp, pick, px.data_ptr(), abi.RenderDebug(0, 0, xyz.data_ptr(), streams.data_ptr()))
+    torch.cuda.synchronize()
+    pv.check_errors()
+    got = xyz.cpu().numpy().astype(np.float64)[:n]
+    r = ref["xyzT"].astype(np.float64)
+    end = streams.cpu().numpy().view(abi.STREAM_DTYPE).reshape(-1)["end_draw"]
+    scale = max(float(np.abs(r[:, :3]).max()), 1e-30)
+    err = np.linalg.norm(got[:, :3] - r[:, :3], axis=1) / np.maximum(np.linalg.norm(r[:, :3], axis=1), 1e-6 * scale)
+    gp, rp = got[:, :3].reshape(-1, spp_p, 3).mean(1), r[:, :3].reshape(-1, spp_p, 3).mean(1)
+    perr = np.linalg.norm(gp - rp, axis=1) / np.maximum(np.linalg.norm(rp, axis=1), 1e-6 * scale)
+    return {"tasks": int(len(pick)), "samples": int(n), "spp": int(spp_p), "oracle_s": t_cpu, "oracle_threads": cores,
+            "max_rel_l2_per_pixel": float(perr.max()), "max_rel_l2_per_sample": float(err.max()), "samples_above_1e-4": int((err > 1e-4).sum()),
+            "rng_end_positions_equal": bool((end == ref["end_draws"]).all()), "tolerance_per_pixel": 1e-4,
+            "ok": bool(perr.max() <= 1e-4 and (end == ref["end_draws"]).all())}
+
+
 def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n=0, **over):
     import torch
     scene = blob.load(os.path.join(GOLD, "scene_%s.bin" % scene_name))
@@ -130,6 +169,8 @@ def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n
                                                "crowded_sub_bin": work["group_deferred_too_few"], "radius_corrections_exhausted": work["group_attempts"]}}
         if "--raw-stats" in sys.argv:
             rec["frame"]["raw_stats"] = work
+        if "--no-parity" not in sys.argv:
+            rec["frame"]["parity"] = parity_leg(torch, pv, scene, params, xres, yres, spp, n_tiles)
     pv.close()
     print(json.dumps(rec), flush=True)
 

@@ -7,8 +7,8 @@ image film) -> RGB.
 
 The file's own Film / Sampler / integrator parameters are used unless overridden.  The surface integrator (direct lighting +
 caustic estimate on matte surfaces) is switched on when the scene asks for "photonmap" and the device path
-covers it (matte triangles only, homogeneous isotropic medium); otherwise Ls = 0 and the image holds the volume term alone --
-the tool says which."""
+covers it (matte and glass surfaces -- the specular recursion included --, homogeneous isotropic medium, no indirect map); otherwise
+Ls = 0 and the image holds the volume term alone -- the tool says which."""
 import argparse
 import importlib
 import os
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def render_scene_file(path, xres=None, yres=None, spp=None, photons=None, shoot_tasks=2048, surface=True, log=print):
+def render_scene_file(path, xres=None, yres=None, spp=None, photons=None, shoot_tasks=2048, surface=True, log=print, caustic_photons=None):
     import torch
     pkg = importlib.import_module("cs348b-pbrt_amd")
     pvol = importlib.import_module("cs348b-pbrt_amd.pvol")
@@ -32,6 +32,8 @@ def render_scene_file(path, xres=None, yres=None, spp=None, photons=None, shoot_
     over = {"keep_surface_photons": 1}
     if photons:
         over["n_volume_photons"] = int(photons)
+    if caustic_photons is not None:
+        over["n_caustic_photons"] = int(caustic_photons)
     params = abi.params_from_blob(scene, **over)
     pv = pvol.PhotonVolume(params)
     try:

@@ -1,5 +1,5 @@
-set -e
-for w in 4 16; do
+
+for w in 16; do
   PVOL_TILE_WAVES=$w timeout -k 10 400 python -m pytest tests/test_gpu_render.py -m gpu -x -q > gpurun_out/b1_render_w$w.log 2>&1; tail -2 gpurun_out/b1_render_w$w.log
 done
 for w in 1 4 8 16; do

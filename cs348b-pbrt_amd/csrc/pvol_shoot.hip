@@ -498,6 +498,8 @@ __device__ int march_grid(PathCtx &C, V3 rayO, V3 dn, float t_i, float *t0io, fl
             if (tt < tb) K = GRID_KMAX + 1;   // does not fit: serial form for this trip
         }
         if (__ballot(K > GRID_KMAX)) { *t0io = t0; return -1; }
+        // (measured on C4's map, 2.05 M photons: 67 s serial -> 22 s in this form; four sample points per trip of the fetch loop with
+        // register accumulators for the bins made the 238-VGPR kernel spill: 43 s)
         float yy = 0.f;
         for (int b = 0; b < NBIN; ++b) {
             const float sT = C.cstT[b];

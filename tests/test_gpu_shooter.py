@@ -41,7 +41,8 @@ def _shoot_both(pvol, orc, scene_name, n_photons, n_tasks, **over):
 @pytest.mark.parametrize("scene_name,n_photons,n_tasks", [("volumescene_h", 1500, 16), ("pinkfloyd", 4000, 4), ("shootbench", 3000, 8),
                                                           ("sphereroom", 3000, 8),         # Shape "sphere": refraction through a glass ball, a partial matte sphere (row f3)
                                                           ("meshroom", 1500, 16),          # 966 triangles: closest hits through the device-built hierarchy (row f4)
-                                                          ("volumescene_hg", 1500, 16)])   # g = 0.6 (row a16): the scattering weight p(wo, wi) / pdf varies
+                                                          ("volumescene_hg", 1500, 16),    # g = 0.6 (row a16): the scattering weight p(wo, wi) / pdf varies
+                                                          ("volumescene_grid16", 1500, 16)])   # VolumeGrid: the lane-per-step march with drawn tau() offsets (march_grid)
 def test_device_shooter_matches_oracle_shooter(pvol, orc, scene_name, n_photons, n_tasks):
     ref, rst, got, gst, pv, o, s, p = _shoot_both(pvol, orc, scene_name, n_photons, n_tasks)
     # integer work counters: identical unless an ulp flipped a decision somewhere

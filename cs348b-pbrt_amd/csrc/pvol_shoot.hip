@@ -50,6 +50,7 @@ struct ShootArgs {
     int keepSurface;
     unsigned long long *stats;  // paths, follow_calls, no_hit, march_steps, interactions, absorbed, split_children, overflow
     int init;                 // 1: seed RNG + Halton tables instead of shooting
+    uint32_t blockPaths;      // paths per task and round (4096: PhotonShootingTask::Run's block, photonshooter.cpp:247)
     int gridVolume;           // the medium is a VolumeGrid: the kernel takes GRID_KMAX x 64 more LDS words (march_grid)
 };
 
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(LANES, WPE) void shoot_kernel(ShootArgs A) {
     C.capS = A.capS; C.capR = A.capR; C.nSurf = C.nRad = 0;
     C.nVol = C.nCaustic = C.nDirect = C.nIndirect = 0;
     C.follow = C.noHit = C.march = C.inter = C.absorbed = C.splitc = C.overflow = 0;
-    const uint32_t blockSize = 4096;
+    const uint32_t blockSize = A.blockPaths;
     unsigned long long paths = 0;
     // the lane's Halton dimension: base and offset of its permutation table (lanes 0..5)
     const uint32_t hBase = lane == 0 ? 2u : lane == 1 ? 3u : lane == 2 ? 5u : lane == 3 ? 7u : lane == 4 ? 11u : 13u;

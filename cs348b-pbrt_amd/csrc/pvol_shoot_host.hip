@@ -29,6 +29,7 @@ struct ShootArgs {
     int keepSurface;
     unsigned long long *stats;
     int init;
+    uint32_t blockPaths;      // paths per task and round (4096: PhotonShootingTask::Run's block, photonshooter.cpp:247)
     int gridVolume;           // the medium is a VolumeGrid: the kernel takes GRID_KMAX x 64 more LDS words (march_grid)
 };
 struct SurfMergeArgs {
@@ -100,8 +101,10 @@ extern "C" void pvol_free_surface_stores(pvol_ctx *c) {
     c->surfKept = false;
 }
 
-extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
-    if (!c || n_tasks == 0 || n_tasks > 65536) return PVOL_E_INVALID;
+extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) { return pvol_preprocess_blocks(c, n_tasks, 4096); }
+
+extern "C" int pvol_preprocess_blocks(pvol_ctx *c, uint32_t n_tasks, uint32_t block_paths) {
+    if (!c || n_tasks == 0 || n_tasks > 65536 || block_paths == 0 || block_paths > 4096) return PVOL_E_INVALID;
     if (!c->haveScene) return PVOL_E_NO_SCENE;
     std::lock_guard<std::recursive_mutex> api(c->apiMu);
     if (!ok(hipSetDevice(c->params.device))) return PVOL_E_NO_DEVICE;
@@ -118,7 +121,8 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     const auto tShoot0 = std::chrono::steady_clock::now();
     c->prepSeconds[0] = c->prepSeconds[1] = 0.0;
     const uint32_t T = n_tasks;
-    const uint32_t blockSize = 4096;
+    const uint32_t blockSize = block_paths;
+    const uint32_t giveUpShot = 4096;   // the reference's constant in its give-up test (photonshooter.cpp:283-290), whatever the block
     const size_t SW = pvol_shoot_state_words();
     const bool keep = c->params.keep_surface_photons != 0;
     // Room for one block of one task.  Spectral splitting stores up to ~3 photons per path but the usual yield is
@@ -143,6 +147,7 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
     A.localPhotons = B.localPhotons; A.localCounts = B.localCounts; A.cap = cap; A.stats = B.stats; A.init = 1;
     A.localSurf = B.localSurf; A.localSurfKind = B.localSurfKind; A.capS = capS; A.localRad = B.localRad; A.capR = capR; A.keepSurface = keep ? 1 : 0;
     A.gridVolume = c->hs.volKind == PVOL_VOLUME_GRID ? 1 : 0;
+    A.blockPaths = blockSize;
     if (!ok(pvol_launch_shoot(&A, 0)) || !ok(hipDeviceSynchronize())) { B.release(false); return PVOL_E_NO_DEVICE; }
     A.init = 0;
     A.stateOut = B.stateB;
@@ -217,8 +222,8 @@ extern "C" int pvol_preprocess(pvol_ctx *c, uint32_t n_tasks) {
             uint32_t &fl = flags[t];
             if (fl & 8u) continue;
             if (abortTasks) { fl |= 8u; continue; }
-            if (nshot > 500000 && (unsuccessful(P.n_caustic_photons, nCaustic, blockSize) || unsuccessful(P.n_indirect_photons, nIndirect, blockSize) ||
-                                   unsuccessful(P.n_volume_photons, nVolume, blockSize))) {
+            if (nshot > 500000 && (unsuccessful(P.n_caustic_photons, nCaustic, giveUpShot) || unsuccessful(P.n_indirect_photons, nIndirect, giveUpShot) ||
+                                   unsuccessful(P.n_volume_photons, nVolume, giveUpShot))) {
                 nVolume = 0; nCaustic = nIndirect = 0; nRadTotal = 0;   // photonshooter.cpp:292-298 erases caustic, indirect, volume, radiance
                 vTask.clear(); vCount.clear(); vOff.clear(); vNshot.clear();
                 sTask.clear(); sN.clear(); sTake.clear(); sOff.clear(); sRad.clear();

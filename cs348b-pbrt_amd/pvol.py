@@ -46,6 +46,7 @@ def lib():
         L.pvol_set_scene.argtypes = [C.c_void_p, C.POINTER(abi.Scene)]
         L.pvol_upload_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32]
         L.pvol_preprocess.argtypes = [C.c_void_p, C.c_uint32]
+        L.pvol_preprocess_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
         L.pvol_photon_count.argtypes = [C.c_void_p, _u32p]
         L.pvol_download_photons.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, C.c_uint32]
         L.pvol_li_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, _f32p, _u32p]
@@ -94,7 +95,7 @@ EXPORTS = ["pvol_abi_version", "pvol_strerror", "pvol_device_count", "pvol_defau
            "pvol_film_add_samples_device", "pvol_film_resolve_device", "pvol_march_kernel_name", "pvol_check_errors", "pvol_get_preprocess_seconds", "pvol_get_accel_info", "pvol_surface_photon_count",
            "pvol_download_surface_photons", "pvol_radiance_photon_count", "pvol_download_radiance_photons",
            "pvol_set_surface_integrator", "pvol_enable_phase_timing", "pvol_get_phase_ms",
-           "pvol_partition_tasks", "pvol_render_frame_ranks"]
+           "pvol_partition_tasks", "pvol_render_frame_ranks", "pvol_preprocess_blocks"]
 
 SHOOT_STAT_NAMES = ["paths", "follow_calls", "no_hit", "march_steps", "interactions", "absorbed", "stored_volume",
                     "stored_caustic", "stored_direct", "stored_indirect", "split_children", "nshot"]
@@ -150,8 +151,12 @@ class PhotonVolume:
         _check(lib().pvol_upload_photons(self._h, p.ctypes.data_as(_f32p), wi.ctypes.data_as(_f32p), alpha.ctypes.data_as(_f32p), n),
                "pvol_upload_photons")
 
-    def preprocess(self, n_tasks=1):
-        _check(lib().pvol_preprocess(self._h, n_tasks), "pvol_preprocess")
+    def preprocess(self, n_tasks=1, block_paths=4096):
+        """PhotonShooter::Preprocess on the device; block_paths < 4096: many small blocks (pvol_preprocess_blocks)."""
+        if block_paths == 4096:
+            _check(lib().pvol_preprocess(self._h, n_tasks), "pvol_preprocess")
+        else:
+            _check(lib().pvol_preprocess_blocks(self._h, n_tasks, block_paths), "pvol_preprocess_blocks")
 
     def preprocess_times(self):
         """(shoot seconds, search-structure build seconds) of the last preprocess()."""

@@ -297,6 +297,16 @@ int pvol_upload_photons(pvol_ctx *ctx, const float *p, const float *wi,
  * round (photonshooter.cpp:280-351) and builds the search structure. */
 int pvol_preprocess(pvol_ctx *ctx, uint32_t n_tasks);
 
+/* The same with `block_paths` (1 .. 4096) paths per virtual task and round instead of PhotonShootingTask::Run's 4096
+ * (photonshooter.cpp:247): the merge rule is unchanged (task order per round, volume photons divided by the running nshot,
+ * :280-351), only finer.  What it is for: a store stops growing at the first merge that fills it, so what is stored overshoots
+ * the request by up to one round = n_tasks x block_paths paths' worth of photons -- with 4096-path blocks a prism scene cannot
+ * use more than a few hundred tasks (C3: 256 waves on a 1024-SIMD chip, and still 6.7 M stored for 4 M asked); with small blocks
+ * thousands of tasks keep the chip busy at the same overshoot.  Not the reference's block size, hence not its photon set:
+ * statistically the same map (tests/test_gpu_shooter.py: counts, flux, spatial and spectral histograms), and still equal to the
+ * oracle photon for photon when the oracle runs the same block size. */
+int pvol_preprocess_blocks(pvol_ctx *ctx, uint32_t n_tasks, uint32_t block_paths);
+
 /* Work counters of the last pvol_preprocess (the figures SURVEY 6 reports for the reference shooter):
  * out[12] = paths, followPhoton calls, calls ending without a surface hit, transmittance-march steps,
  * volume interactions, absorbed, stored volume / caustic / direct / indirect photons, spectral-split

@@ -49,6 +49,7 @@ def lib():
         L.orc_get_counters.argtypes = [C.c_void_p, _u64p, C.c_int]
         L.orc_lphoton_batch.argtypes = [C.c_void_p, _f32p, _f32p, C.c_uint32, _f32p]
         L.orc_shoot.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.orc_shoot_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
         L.orc_get_shoot_stats.argtypes = [C.c_void_p, _u64p]
         L.orc_keep_surface_photons.argtypes = [C.c_void_p, C.c_int]
         L.orc_keep_surface_photons.restype = None
@@ -178,8 +179,8 @@ class Oracle:
         a = np.ascontiguousarray(caustic[2], np.float32).reshape(-1)
         lib().orc_set_surface_integrator(self._h, 1, n_used, max_dist, int(final_gather), _p(p, _f32p), _p(w, _f32p), _p(a, _f32p), p.size // 3, int(n_paths))
 
-    def shoot(self, n_tasks=1, n_threads=1):
-        return lib().orc_shoot(self._h, n_tasks, n_threads)
+    def shoot(self, n_tasks=1, n_threads=1, block_paths=4096):
+        return lib().orc_shoot_blocks(self._h, n_tasks, n_threads, block_paths)
 
     def keep_surface_photons(self, on=True):
         lib().orc_keep_surface_photons(self._h, int(on))

@@ -178,9 +178,12 @@ int orc_lphoton_batch(orc_ctx *c, const float *pts, const float *w, uint32_t n, 
 
 // PhotonShooter::Preprocess (photonshooter.cpp:457-526) with n_tasks virtual tasks merged in
 // task order per block round; n_tasks == 1 is the reference at --ncores 1.
-int orc_shoot(orc_ctx *c, uint32_t n_tasks, int n_threads) {
+int orc_shoot_blocks(orc_ctx *c, uint32_t n_tasks, int n_threads, uint32_t block_paths);
+int orc_shoot(orc_ctx *c, uint32_t n_tasks, int n_threads) { return orc_shoot_blocks(c, n_tasks, n_threads, 4096); }
+// the same with `block_paths` paths per task and round (the product's pvol_preprocess_blocks)
+int orc_shoot_blocks(orc_ctx *c, uint32_t n_tasks, int n_threads, uint32_t block_paths) {
     std::vector<Photon> vol;
-    int rc = shoot_photons(c->scene, c->params, n_tasks, n_threads, &vol, &c->shoot_stats, c->keep_surface ? &c->surf : 0);
+    int rc = shoot_photons(c->scene, c->params, n_tasks, n_threads, &vol, &c->shoot_stats, c->keep_surface ? &c->surf : 0, block_paths);
     c->photons.swap(vol);
     delete c->map;
     c->map = c->photons.size() ? new KdTree(c->photons) : 0;

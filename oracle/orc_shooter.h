@@ -316,9 +316,8 @@ inline void follow_photon(const ShootShared &S, ShootTask &T, Ray photonRay, Hit
 }
 
 // One block of PhotonShootingTask::Run's loop body (photonshooter.cpp:246-277)
-inline void shoot_block(const ShootShared &S, ShootTask &T) {
+inline void shoot_block(const ShootShared &S, ShootTask &T, uint32_t blockSize = 4096) {
     const Scene &sc = *S.scene;
-    const uint32_t blockSize = 4096;
     int nLights = (int)sc.lights.size();
     for (uint32_t i = 0; i < blockSize; ++i) {
         float u[6];
@@ -345,7 +344,7 @@ inline void shoot_block(const ShootShared &S, ShootTask &T) {
 // reference's mutex-ordered merge (photonshooter.cpp:280-351) made deterministic; nTasks == 1
 // reproduces --ncores 1 exactly.
 inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t nTasks, int nThreads,
-                         std::vector<Photon> *volumeOut, ShootStats *stats, SurfaceStores *surf = 0) {
+                         std::vector<Photon> *volumeOut, ShootStats *stats, SurfaceStores *surf = 0, uint32_t blockSize = 4096) {
     volumeOut->clear();
     if (surf) *surf = SurfaceStores();
     *stats = ShootStats();
@@ -377,7 +376,10 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
     bool abortTasks = false;
     uint32_t stallRounds = 0;
     int rc = 0;
-    const uint32_t blockSize = 4096;
+    // blockSize: paths per task and round.  4096 is the reference's (photonshooter.cpp:247); the product's "many small blocks" mode
+    // (pvol_preprocess_blocks) runs the same loop with less -- same merge rule, finer granularity -- and is restated here so that
+    // the device can be held against it photon for photon in that mode too.  The give-up test keeps the reference's constant.
+    const uint32_t giveUpShot = 4096;
     auto unsuccessful = [](uint32_t needed, uint64_t found, uint32_t shot) {  // photonshooter.cpp:37-39
         return (found < needed && (found == 0 || found < shot / 1024));
     };
@@ -386,21 +388,21 @@ inline int shoot_photons(const Scene &scene, const pvol_params &params, uint32_t
         for (auto *t : tasks) if (!t->finished) live.push_back(t);
         if (live.empty()) break;
         // run one block per live task (in parallel; tasks share nothing while shooting)
-        if (nThreads <= 1 || live.size() == 1) { for (auto *t : live) shoot_block(S, *t); }
+        if (nThreads <= 1 || live.size() == 1) { for (auto *t : live) shoot_block(S, *t, blockSize); }
         else {
             std::atomic<size_t> next(0);
             std::vector<std::thread> th;
             for (int k = 0; k < nThreads; ++k)
-                th.emplace_back([&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= live.size()) break; shoot_block(S, *live[i]); } });
+                th.emplace_back([&]() { for (;;) { size_t i = next.fetch_add(1); if (i >= live.size()) break; shoot_block(S, *live[i], blockSize); } });
             for (auto &x : th) x.join();
         }
         // merge in task order (photonshooter.cpp:280-351)
         const uint64_t before[3] = {nCaustic, nIndirect, (uint64_t)volumeOut->size()};
         for (auto *t : live) {
             if (abortTasks) { t->finished = true; continue; }
-            if (nshot > 500000 && (unsuccessful(params.n_caustic_photons, nCaustic, blockSize) ||
-                                   unsuccessful(params.n_indirect_photons, nIndirect, blockSize) ||
-                                   unsuccessful(params.n_volume_photons, volumeOut->size(), blockSize))) {
+            if (nshot > 500000 && (unsuccessful(params.n_caustic_photons, nCaustic, giveUpShot) ||
+                                   unsuccessful(params.n_indirect_photons, nIndirect, giveUpShot) ||
+                                   unsuccessful(params.n_volume_photons, volumeOut->size(), giveUpShot))) {
                 volumeOut->clear(); nCaustic = nIndirect = 0;
                 if (surf) { surf->caustic.clear(); surf->indirect.clear(); surf->radiance.clear(); }
                 abortTasks = true; t->finished = true; rc = PVOL_E_SHOOT_FAILED;

@@ -22,17 +22,17 @@ def pvol():
     return m
 
 
-def _shoot_both(pvol, orc, scene_name, n_photons, n_tasks, **over):
+def _shoot_both(pvol, orc, scene_name, n_photons, n_tasks, block_paths=4096, **over):
     s = load_scene(scene_name)
     h = abi.SceneHolder(s)
     p = abi.params_from_blob(s, n_volume_photons=n_photons, **over)
     o = orc.Oracle(h, p)
-    assert o.shoot(n_tasks, 8) == 0
+    assert o.shoot(n_tasks, 8, block_paths) == 0
     ref = o.get_photons()
     rst = o.shoot_stats()
     pv = pvol.PhotonVolume(p)
     pv.set_scene(h)
-    pv.preprocess(n_tasks)
+    pv.preprocess(n_tasks, block_paths)
     got = pv.download_photons()
     gst = pv.shoot_stats()
     return ref, rst, got, gst, pv, o, s, p
@@ -173,3 +173,62 @@ def test_a_store_that_stops_growing_ends_the_pass(pvol, orc):
         assert pv.shoot_stats()["nshot"] == o.shoot_stats()["nshot"]
     finally:
         pv.close()
+
+
+@pytest.mark.parametrize("scene_name,n_photons,n_tasks,block", [("pinkfloyd", 4000, 64, 128), ("volumescene_h", 1500, 64, 512)])
+def test_small_block_mode_matches_the_oracle_with_the_same_blocks(pvol, orc, scene_name, n_photons, n_tasks, block):
+    """pvol_preprocess_blocks: many virtual tasks with fewer than 4096 paths per round (what lets a prism scene use thousands of
+    waves without overshooting the request).  The merge rule is PhotonShootingTask::Run's; with the oracle running the same block
+    size the device still equals it photon for photon."""
+    ref, rst, got, gst, pv, o, s, p = _shoot_both(pvol, orc, scene_name, n_photons, n_tasks, block_paths=block)
+    for k in ["paths", "nshot", "stored_volume", "stored_caustic", "stored_direct", "stored_indirect"]:
+        assert gst[k] == rst[k], (k, gst[k], rst[k])
+    assert gst["paths"] % block == 0
+    assert len(got[0]) == len(ref[0]) >= n_photons
+    np.testing.assert_allclose(got[0], ref[0], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=2e-5)
+    typical = float(np.median(np.abs(ref[2]).max(axis=1)))
+    np.testing.assert_allclose(got[2], ref[2], rtol=2e-4, atol=1e-5 * typical)
+    pv.close()
+
+
+def test_small_block_mode_is_statistically_the_same_map(pvol):
+    """The validation SURVEY 7 asks of a mode that is not the reference's block size: against the 4096-path-block map of the same
+    scene (pinkfloyd: spectral splitting, two lights) -- photons per path, total flux, where the photons lie (a 12^3 histogram over
+    the scene) and which wavelengths they carry (30-bin histogram of the monochromatic photons) -- and the overshoot it is for."""
+    s = load_scene("pinkfloyd")
+    want = 400000
+    maps = {}
+    for tag, tasks, block in (("ref", 64, 4096), ("small", 2048, 16)):
+        pv = pvol.PhotonVolume(abi.params_from_blob(s, n_volume_photons=want, n_caustic_photons=0))
+        pv.set_scene(abi.SceneHolder(s))
+        pv.preprocess(tasks, block)
+        maps[tag] = (pv.download_photons(), pv.shoot_stats())
+        pv.close()
+    (pr, wr, ar), sr = maps["ref"]
+    (ps, ws, as_), ss = maps["small"]
+    # a store stops growing at the first merge that fills it, task by task (photonshooter.cpp:336-338): what is stored overshoots the
+    # request by up to ~two rounds' worth -- 64 x 4096 paths a round against 2048 x 16
+    assert len(pr) > 1.5 * want and want <= len(ps) < 1.3 * want, (len(pr), len(ps))
+    rate_r, rate_s = len(pr) / sr["paths"], len(ps) / ss["paths"]
+    assert abs(rate_s / rate_r - 1) < 0.05, (rate_r, rate_s)                          # stored photons per emitted path
+    # flux: a merged block's photons are divided by the RUNNING nshot (photonshooter.cpp:333) -- block j of B by j x blockPaths -- so the
+    # map's total flux is (photons per path) x (mean emitted weight) x H(B), the B-th harmonic number: it depends on how many blocks
+    # were merged.  That is the reference's own rule (its 8-thread map is brighter than its 1-thread map for the same reason); the two
+    # modes must agree once H(B) is divided out.
+    def harmonic(n):
+        return float(np.log(n) + 0.5772156649 + 0.5 / n)
+    Br, Bs = sr["paths"] / 4096.0, ss["paths"] / 16.0
+    fr, fs = float(ar.sum(dtype=np.float64)) / harmonic(Br), float(as_.sum(dtype=np.float64)) / harmonic(Bs)
+    assert abs(fs / fr - 1) < 0.1, (fr, fs, Br, Bs)
+    lo, hi = s["world"][:3], s["world"][3:]
+
+    def hist3(p):
+        h, _ = np.histogramdd(p, bins=12, range=list(zip(lo, hi)))
+        return h.ravel() / len(p)
+    assert np.corrcoef(hist3(pr), hist3(ps))[0, 1] > 0.995                            # same beams, same fog
+    mono_r, mono_s = (ar != 0).sum(1) == 1, (as_ != 0).sum(1) == 1
+    assert abs(mono_r.mean() - mono_s.mean()) < 0.02                                  # share of monochromatic photons (spectral split)
+    lam_r = np.bincount(np.argmax(ar[mono_r] != 0, axis=1), minlength=30) / mono_r.sum()
+    lam_s = np.bincount(np.argmax(as_[mono_s] != 0, axis=1), minlength=30) / mono_s.sum()
+    assert np.abs(lam_r - lam_s).max() < 0.01, np.abs(lam_r - lam_s).max()            # which wavelengths

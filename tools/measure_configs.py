@@ -105,7 +105,7 @@ def parity_leg(torch, pv, scene, params, xres, yres, spp, n_tiles, n_pick=16, sp
             "ok": bool(perr.max() <= 1e-4 and (end == ref["end_draws"]).all())}
 
 
-def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n=0, **over):
+def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n=0, block_paths=4096, **over):
     import torch
     scene = blob.load(os.path.join(GOLD, "scene_%s.bin" % scene_name))
     if density_n:
@@ -114,11 +114,11 @@ def run(name, scene_name, n_photons, tasks, note, li=None, frame=None, density_n
     pv = pvol.PhotonVolume(params)
     pv.set_scene(abi.SceneHolder(scene))
     t = time.perf_counter()
-    pv.preprocess(tasks)
+    pv.preprocess(tasks, block_paths)
     t_shoot = time.perf_counter() - t
     shoot_s, build_s = pv.preprocess_times()
     st_sh = pv.shoot_stats()
-    rec = {"config": name, "scene": scene_name, "note": note, "photons": pv.photon_count(), "photons_requested": n_photons, "shoot_tasks": tasks,
+    rec = {"config": name, "scene": scene_name, "note": note, "photons": pv.photon_count(), "photons_requested": n_photons, "shoot_tasks": tasks, "shoot_block_paths": block_paths,
            "shoot_s": shoot_s, "grid_build_s": build_s, "shoot_Mpaths_per_s": st_sh["paths"] / shoot_s / 1e6,
            "shoot_stored_Mphotons_per_s": st_sh["stored_volume"] / shoot_s / 1e6, "shoot_Mmarch_steps_per_s": st_sh["march_steps"] / shoot_s / 1e6,
            "nused": params.n_used, "maxdist": params.max_dist, "stepsize": params.step_size}
@@ -203,9 +203,10 @@ if __name__ == "__main__":
         run("C1-literal", "volumescene_rainbow", 100000, 2048, "config 1 as shipped (rainbow volume: no gather), stated size", li=(256, 256, 16),
             frame=(256, 256, 16, True))
     if want("C3"):
-        run("C3", "pinkfloyd", 4000000, 256, "config 3: pinkfloyd 1920x1080, 4 M photons, nused 500, two lights, on ONE MI355X; frame at %s" %
+        # map: 4096 virtual tasks x 32-path blocks (pvol_preprocess_blocks): 4096 waves, a round is 131 k paths (round 2: 256 tasks x 4096)
+        run("C3", "pinkfloyd", 4000000, 4096, "config 3: pinkfloyd 1920x1080, 4 M photons, nused 500, two lights, on ONE MI355X; frame at %s" %
             ("512 spp (stated)" if full else "%d spp instead of 512" % (spp_over[0] if spp_over else 8)), li=(480, 270, 4),
-            frame=(1920, 1080, 512 if full else (spp_over[0] if spp_over else 8), full), n_caustic_photons=0)
+            frame=(1920, 1080, 512 if full else (spp_over[0] if spp_over else 8), full), n_caustic_photons=0, block_paths=32)
     if want("C4"):
         run("C4", "volumescene_grid16", 2000000, 16384, "config 4: 128^3 VolumeGrid (generated here), 2 M photons; frame 256x256 at %s" %
             ("1024 spp (stated)" if full else "64 spp instead of 1024"), li=(128, 128, 8),

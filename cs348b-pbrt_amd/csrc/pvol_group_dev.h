@@ -55,7 +55,7 @@ struct GroupLds {
     float *miniD;           // [GRP_MINI][64] values of the k-th's bin, one column per lane (U region)
     float *ubuf;            // GRP_CH scatter offsets (U region)
     unsigned short *order;  // GRP_CH: chunk-local ray index by rank of scatter offset
-    float *cst;             // 9 x 32 floats: sigA, sigS, le, albedo, light-0 intensity, 1/sigS, CIE X, Y, Z weights
+    float *cst;             // 12 x 32 floats: sigA, sigS, le, albedo, light-0 intensity, 1/sigS, CIE X, Y, Z weights, sigT, sigA le, albedo / sigS
     float *trows;           // GRP_TRI_ROWS x 16 floats: per-triangle shadow-ray precomputation for a distant light
     float *lint;            // PVOL_MAX_LIGHTS x 32 floats: every light's intensity spectrum (REPLAY: the light differs per lane and step)
 };
@@ -170,6 +170,10 @@ __device__ __forceinline__ int stage_bucket(const DevScene &S, Gather &G, float 
 }
 
 typedef float nf4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef GRP_FLUX_MFMA
+#define GRP_FLUX_MFMA 1   // the flux sums of li_group_kernel on the matrix pipe (0: v_pk_fma_f32 with scalar-cache rows, the round-2 form)
+#endif
 
 // OR over the wave, every lane gets it (DPP + permlane swaps, no LDS)
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
@@ -192,17 +196,38 @@ __device__ __forceinline__ uint32_t grp_bin(float d2, float scale, float Tl) {
     return bin;
 }
 
+typedef float nf2 __attribute__((ext_vector_type(2)));
+// two coordinates minus one per-lane value: ONE v_pk_add_f32 with the subtrahend negated and taken from the low (x) or high (y)
+// half of the pair pp for both results -- a + (-b) is a - b bit for bit; the compiler itself writes two v_sub_f32 here
+__device__ __forceinline__ nf2 pk_sub_lo(nf2 a, nf2 pp) {
+    nf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(pp));
+    return r;
+}
+__device__ __forceinline__ nf2 pk_sub_hi(nf2 a, nf2 pp) {
+    nf2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(pp));
+    return r;
+}
+// DistanceSquared(photon.p, p) (kdtree.h:180) of four bucket photons: same operations in the same order per element
+__device__ __forceinline__ nf4 grp_dist4(nf4 X, nf4 Y, nf4 Z, nf2 pxy, nf2 pz_) {
+    const nf2 x0 = pk_sub_lo(__builtin_shufflevector(X, X, 0, 1), pxy), x1 = pk_sub_lo(__builtin_shufflevector(X, X, 2, 3), pxy);
+    const nf2 y0 = pk_sub_hi(__builtin_shufflevector(Y, Y, 0, 1), pxy), y1 = pk_sub_hi(__builtin_shufflevector(Y, Y, 2, 3), pxy);
+    const nf2 z0 = pk_sub_lo(__builtin_shufflevector(Z, Z, 0, 1), pz_), z1 = pk_sub_lo(__builtin_shufflevector(Z, Z, 2, 3), pz_);
+    const nf2 d0 = x0 * x0 + y0 * y0 + z0 * z0, d1 = x1 * x1 + y1 * y1 + z1 * z1;
+    return nf4{d0.x, d0.y, d1.x, d1.y};
+}
+
 // Pass 1: per-lane histogram of DistanceSquared over the bucket (padded to a multiple of four with far-away sentinels).
 template <bool EXACT>
-__device__ __forceinline__ void grp_pass1(const float *bX, const float *bY, const float *bZ, int Mb, nf4 px4, nf4 py4, nf4 pz4, float scale,
+__device__ __forceinline__ void grp_pass1(const float *bX, const float *bY, const float *bZ, int Mb, nf2 pxy, nf2 pz_, float scale,
                                           float Tl, uint32_t *histLane) {
     nf4 nX = *reinterpret_cast<const nf4 *>(bX), nY = *reinterpret_cast<const nf4 *>(bY), nZ = *reinterpret_cast<const nf4 *>(bZ);
     for (int c0 = 0; c0 < Mb; c0 += 4) {
         // the next quartet's coordinates are requested before this one's arithmetic (the padded bucket makes the read past
-        // the end harmless); DistanceSquared(photon.p, p) (kdtree.h:180): same operations in the same order per element
-        const nf4 dx_ = nX - px4, dy_ = nY - py4, dz_ = nZ - pz4;
+        // the end harmless)
+        const nf4 dd = grp_dist4(nX, nY, nZ, pxy, pz_);
         nX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); nY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); nZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
-        const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t bin = grp_bin<EXACT>(dd[u], scale, Tl);
@@ -211,30 +236,57 @@ __device__ __forceinline__ void grp_pass1(const float *bX, const float *bY, cons
     }
 }
 
-// Pass 2: per-lane bit masks over the bucket slots: lt = "bin < bstar", le = "bin <= bstar".
+// The smallest float x >= 0 with grp_bin(x) >= b.  grp_bin is monotone, so "bin < b" IS "d2 < x": pass 2 compares distances with two
+// such thresholds and never forms a bin.  *okp is cleared if the few steps around b / scale did not land on it (never seen; the
+// lookup would go to the hand-over list).
 template <bool EXACT>
-__device__ __forceinline__ void grp_pass2(const float *bX, const float *bY, const float *bZ, int Mb, nf4 px4, nf4 py4, nf4 pz4, float scale,
-                                          float Tl, uint32_t bstar, uint32_t (&lt)[GRP_NW], uint32_t (&le)[GRP_NW], float &dmax) {
+__device__ __forceinline__ float grp_theta(uint32_t b, float scale, float Tl, bool *okp) {
+    if (b == 0u) return 0.f;
+    if (b > (uint32_t)GRP_BINS) return INFINITY;
+    float x = (float)b / scale;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float xm = __uint_as_float(__float_as_uint(x) - 1u);
+        if (x > 0.f && grp_bin<EXACT>(xm, scale, Tl) >= b) x = xm;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (grp_bin<EXACT>(x, scale, Tl) < b) x = __uint_as_float(__float_as_uint(x) + 1u);
+    const bool good = grp_bin<EXACT>(x, scale, Tl) >= b && (!(x > 0.f) || grp_bin<EXACT>(__uint_as_float(__float_as_uint(x) - 1u), scale, Tl) < b);
+    if (!good) *okp = false;
+    return x;
+}
+
+// m = 2 m + (d2 < th): one compare and one add-with-carry per slot; the slots of a word arrive most significant first
+__device__ __forceinline__ void grp_bit_lt(uint32_t &m, float d2, float th) {
+    asm("v_cmp_lt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(d2), "v"(th) : "vcc");
+}
+
+// Pass 2: per-lane bit masks over the bucket slots: lt = "bin < bstar" = "d2 < th1", le = "bin <= bstar" = "d2 < th2".
+template <bool EXACT>
+__device__ __forceinline__ void grp_pass2(const float *bX, const float *bY, const float *bZ, int Mb, nf2 pxy, nf2 pz_, float th1, float th2,
+                                          uint32_t (&lt)[GRP_NW], uint32_t (&le)[GRP_NW], float &dmax) {
 #pragma unroll
     for (int wd = 0; wd < GRP_NW; ++wd) {
         uint32_t mlt = 0u, mle = 0u;
         if (wd * 32 < Mb) {   // wave-uniform
             const int cend = min(Mb, wd * 32 + 32);
             nf4 nX = *reinterpret_cast<const nf4 *>(bX + wd * 32), nY = *reinterpret_cast<const nf4 *>(bY + wd * 32), nZ = *reinterpret_cast<const nf4 *>(bZ + wd * 32);
+            int n = 0;
             for (int c0 = wd * 32; c0 < cend; c0 += 4) {
-                const nf4 dx_ = nX - px4, dy_ = nY - py4, dz_ = nZ - pz4;
+                const nf4 dd = grp_dist4(nX, nY, nZ, pxy, pz_);
                 nX = *reinterpret_cast<const nf4 *>(bX + c0 + 4); nY = *reinterpret_cast<const nf4 *>(bY + c0 + 4); nZ = *reinterpret_cast<const nf4 *>(bZ + c0 + 4);
-                const nf4 dd = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const uint32_t bin = grp_bin<EXACT>(dd[u], scale, Tl);
-                    const uint32_t isLt = bin < bstar ? 1u : 0u, isLe = bin <= bstar ? 1u : 0u;
-                    const int sh = (c0 + u) & 31;   // wave-uniform shift
-                    mlt |= isLt << sh;
-                    mle |= isLe << sh;
-                    if (EXACT) dmax = fmaxf(dmax, isLt ? dd[u] : 0.f);
+                    grp_bit_lt(mlt, dd[u], th1);
+                    grp_bit_lt(mle, dd[u], th2);
+                    if (EXACT) dmax = fmaxf(dmax, dd[u] < th1 ? dd[u] : 0.f);
                 }
+                n += 4;
             }
+            // slot i of the n processed sits at bit n - 1 - i: reverse, then drop the 32 - n empty places
+            mlt = __builtin_bitreverse32(mlt) >> (32 - n);
+            mle = __builtin_bitreverse32(mle) >> (32 - n);
         }
         lt[wd] = mlt;
         le[wd] = mle;
@@ -264,7 +316,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
     L.miniD = reinterpret_cast<float *>(U);
     L.ubuf = reinterpret_cast<float *>(U);
     L.cst = reinterpret_cast<float *>(U + GRP_U_BYTES);
-    L.trows = L.cst + 9 * 32;
+    L.trows = L.cst + 12 * 32;
     L.lint = L.trows + GRP_TRI_ROWS * 16;
     for (int i = lane; i < PREV_N; i += LANES) prevRk[i] = 0.f;
     const int q = lane & 7;
@@ -290,10 +342,13 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
         L.cst[192 + lane] = lane < 30 ? S.cieX[lane] : 0.f;
         L.cst[224 + lane] = lane < 30 ? S.cieY[lane] : 0.f;
         L.cst[256 + lane] = lane < 30 ? S.cieZ[lane] : 0.f;
+        L.cst[288 + lane] = a + s;
+        L.cst[320 + lane] = a * S.le[lane];
+        L.cst[352 + lane] = lane < 30 ? __fdividef(s, a + s) * __builtin_amdgcn_rcpf(s) : 0.f;
     }
     __syncthreads();
     const f4 *cA = reinterpret_cast<const f4 *>(L.cst), *cS = cA + 8, *cLe = cA + 16, *cAl = cA + 24, *cI = cA + 32, *cRs = cA + 40;
-    const f4 *cX = cA + 48, *cY = cA + 56, *cZ = cA + 64;
+    const f4 *cX = cA + 48, *cY = cA + 56, *cZ = cA + 64, *cT = cA + 72, *cAL = cA + 80, *cAR = cA + 88;
     const bool rowsOK = !REPLAY && nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS && !S.bvhNodes && !S.nSpheres;
     if (rowsOK) tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), L.trows, lane);
     const int k = S.nUsed;
@@ -483,9 +538,20 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 const float kRem = -1.442695041f * (totalLen - cumLen);   // exp(-sigma_t R_j) = exp2(sigma_t * kRem)
                 const float stepD = step * dens;
                 // ---- k-NN gather of the group
+                // Raw flux sums of the step.  GRP_FLUX_MFMA: two 32 x 32 fp32 matrix accumulators (v_mfma_f32_32x32x2_f32, bit for bit an
+                // fmaf chain): rows = bins, columns = rays.  Lane l holds column (ray) l & 31 of CA (rays 0..31) and of CB (rays 32..63),
+                // register i = bin 8 (i >> 2) + (i & 3) + 4 (l >> 5).  After the attempts 16 v_permlane32_swap leave every lane its OWN
+                // ray's 32 bins: CA[i] = bin 8 (i >> 2) + (i & 3), CB[i] = the same + 4.
+#if GRP_FLUX_MFMA
+                f32x16 CA, CB;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) { CA[b] = 0.f; CB[b] = 0.f; }
+                bool anyFlux = false;   // wave-uniform
+#else
                 float acc[32];
 #pragma unroll
                 for (int b = 0; b < 32; ++b) acc[b] = 0.f;
+#endif
                 float rk = 0.f;
                 int nFoundLane = k;
                 const bool need = inP && S.nPhotons > 0u && useLiiAny;
@@ -557,14 +623,14 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             fullR = !(Tl < S.maxDistSq);
                         }
                         const unsigned long long tp1 = STATS ? stamp() : 0ull;
-                        const nf4 px4 = {p.x, p.x, p.x, p.x}, py4 = {p.y, p.y, p.y, p.y}, pz4 = {p.z, p.z, p.z, p.z};
+                        const nf2 pxy = {p.x, p.y}, pz_ = {p.z, p.z};
                         // ---- pass 1: histogram over [0, Tl)
                         const float scale = needP ? (float)GRP_BINS / Tl : 0.f;   // lanes without a lookup put everything in the overflow word
                         const bool exact = __ballot(needP && fullR) != 0ull;
 #pragma unroll
                         for (int wd = 0; wd <= GRP_BINS / 8; ++wd) histLane[wd * LANES] = 0u;
-                        if (exact) grp_pass1<true>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, histLane);
-                        else grp_pass1<false>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, histLane);
+                        if (exact) grp_pass1<true>(bX, bY, bZ, Mb, pxy, pz_, scale, Tl, histLane);
+                        else grp_pass1<false>(bX, bY, bZ, Mb, pxy, pz_, scale, Tl, histLane);
                         // ---- prefix scan: word of the k-th, then its nibble
                         int cum = 0, wsel = -1, cumWord = 0;
                         uint32_t selBits = 0u;
@@ -616,9 +682,14 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             uint32_t mem[GRP_NW], le[GRP_NW];
                             float dmax = 0.f;
                             const uint32_t bstar = shortSet ? (uint32_t)GRP_BINS : (ok ? (uint32_t)bstarI : 0u);
+                            float th1, th2;
+                            bool thOK = true;
+                            if (exact) { th1 = grp_theta<true>(bstar, scale, Tl, &thOK); th2 = grp_theta<true>(bstar + 1u, scale, Tl, &thOK); }
+                            else { th1 = grp_theta<false>(bstar, scale, Tl, &thOK); th2 = grp_theta<false>(bstar + 1u, scale, Tl, &thOK); }
+                            ok = ok && thOK;
                             __syncthreads();
-                            if (exact) grp_pass2<true>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, bstar, mem, le, dmax);
-                            else grp_pass2<false>(bX, bY, bZ, Mb, px4, py4, pz4, scale, Tl, bstar, mem, le, dmax);
+                            if (exact) grp_pass2<true>(bX, bY, bZ, Mb, pxy, pz_, th1, th2, mem, le, dmax);
+                            else grp_pass2<false>(bX, bY, bZ, Mb, pxy, pz_, th1, th2, mem, le, dmax);
                             // ---- the photons of bin b*: their exact values into the lane's mini list (slot order)
                             int nb = 0;
 #pragma unroll
@@ -676,7 +747,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                     }
                                 }
                             }
-                            if (shortSet) { ok = true; rkC = dmax; }
+                            if (shortSet) { ok = thOK; rkC = dmax; }
                             const unsigned long long tp3 = STATS ? stamp() : 0ull;
                             if (STATS) wc.cySelect += tp3 - tp1;
                             // ---- flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
@@ -690,6 +761,103 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             // lane b (and b + 32 for every second slot) adds bin b of their rows, one coalesced 128-B row per
                             // half-wave load -- and handed to the lanes by 30 readlanes; the per-lane loop below then runs over
                             // the remaining slots only.  Addition order changes, nothing else.
+#if GRP_FLUX_MFMA
+                            // ---- flux on the matrix pipe.  A = alpha rows (lane l: bin l & 31 of the slot of its half-wave: one coalesced
+                            // 128-B row per half-wave and load), B = member bits of ray l & 31 for that slot as 0.f / 1.f (the upper
+                            // half-wave's copy of a ray's word comes from ONE v_permlane32_swap per 32 slots): D = A B + C adds a row to exactly
+                            // the rays it is a member for.  Two slots per instruction, rays 0..31 into CA, rays 32..63 into CB.
+                            const int half = lane >> 5, binL = lane & 31;
+                            typedef const __attribute__((address_space(1))) float gfloat;   // global_load, not flat_load
+                            gfloat *alphaF = (gfloat *)(S.alpha4);
+                            if (GRP_CORE_MIN < GRP_CAP) {
+                                const bool anyOk = __ballot(ok) != 0ull;
+                                int nCore = 0;
+                                uint32_t coreW[GRP_NW];
+#pragma unroll
+                                for (int wd = 0; wd < GRP_NW; ++wd) {
+                                    coreW[wd] = 0u;
+                                    if (wd * 32 >= Mb || !anyOk) continue;
+                                    coreW[wd] = (uint32_t)__builtin_amdgcn_readfirstlane((int)~wave_or(ok ? ~mem[wd] : 0u));
+                                    nCore += __builtin_popcount(coreW[wd]);
+                                }
+                                if (nCore >= GRP_CORE_MIN) {
+                                    // slots that are members for EVERY served lane: their rows are summed once (two rows per load, lane = bin)
+                                    // and the sum enters as one more "row" whose member bits are the served lanes
+                                    uint32_t *clist = reinterpret_cast<uint32_t *>(L.miniD);
+                                    int basePos = 0;
+#pragma unroll
+                                    for (int r2 = 0; r2 < GRP_NW / 2; ++r2) {
+                                        if (r2 * 64 >= Mb) continue;
+                                        const unsigned long long c64 = (unsigned long long)coreW[2 * r2] | ((unsigned long long)coreW[2 * r2 + 1] << 32);
+                                        if ((c64 >> lane) & 1ull) clist[basePos + (int)lanes_below(c64, lane)] = __float_as_uint(bI[r2 * 64 + lane]);
+                                        basePos += __popcll(c64);
+                                    }
+                                    __syncthreads();
+                                    float cs = 0.f;
+                                    for (int c0 = 0; c0 < nCore; c0 += 16) {   // up to 16 rows in flight per trip
+                                        float v[8];
+#pragma unroll
+                                        for (int q2 = 0; q2 < 8; ++q2) {
+                                            const int at = c0 + 2 * q2 + half;
+                                            const bool on = at < nCore;
+                                            const uint32_t idx = clist[on ? at : 0];
+                                            const float w = alphaF[(size_t)idx * 32 + binL];
+                                            v[q2] = on ? w : 0.f;
+                                        }
+                                        cs += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                                    }
+                                    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs), __float_as_uint(cs), false, false); cs = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+                                    const uint32_t okW = ok ? 1u : 0u;
+                                    auto ro = __builtin_amdgcn_permlane32_swap(okW, okW, false, false);
+                                    const float fA = half ? 0.f : (float)ro[0], fB = half ? 0.f : (float)ro[1];
+                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(cs, fA, CA, 0, 0, 0);
+                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(cs, fB, CB, 0, 0, 0);
+                                    anyFlux = true;
+#pragma unroll
+                                    for (int wd = 0; wd < GRP_NW; ++wd) mem[wd] &= ~coreW[wd];
+                                    __syncthreads();
+                                }
+                            }
+#pragma unroll
+                            for (int wd = 0; wd < GRP_NW; ++wd) {
+                                if (wd * 32 >= Mb) continue;
+                                const uint32_t mine = ok ? mem[wd] : 0u;
+                                auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+                                const uint32_t W1 = sw[0], W2 = sw[1];   // every lane: the word of ray (l & 31), of ray 32 + (l & 31)
+                                uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)(wave_or(W1 | W2)));
+                                if (!any) continue;
+                                anyFlux = true;
+                                const int idxW = (int)__float_as_uint(bI[wd * 32 + binL]);   // this word's photon indices, one per lane
+                                while (any) {   // four slot pairs per trip: their rows are requested before the first is used
+                                    int sel[4];
+                                    float av[4];
+                                    bool on[4], two[4];
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) {
+                                        on[t] = any != 0u;
+                                        const int b0 = on[t] ? __builtin_ctz(any) : 0;
+                                        any &= any - 1u;
+                                        two[t] = any != 0u;
+                                        const int b1 = two[t] ? __builtin_ctz(any) : b0;
+                                        any &= any - 1u;   // 0 & anything stays 0
+                                        sel[t] = half ? b1 : b0;
+                                        av[t] = 0.f;
+                                        if (on[t]) {   // wave-uniform
+                                            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(idxW, b0), i1 = (uint32_t)__builtin_amdgcn_readlane(idxW, b1);
+                                            av[t] = alphaF[(size_t)(half ? i1 : i0) * 32 + binL];
+                                        }
+                                    }
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t) {
+                                        if (!on[t]) continue;   // wave-uniform
+                                        const bool live = two[t] || !half;   // an odd slot out: the upper half-wave contributes nothing
+                                        const float f1 = live ? (float)((W1 >> sel[t]) & 1u) : 0.f, f2 = live ? (float)((W2 >> sel[t]) & 1u) : 0.f;
+                                        CA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], f1, CA, 0, 0, 0);
+                                        CB = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], f2, CB, 0, 0, 0);
+                                    }
+                                }
+                            }
+#else
                             if (GRP_CORE_MIN < GRP_CAP) {
                                 const bool anyOk = __ballot(ok) != 0ull;
                                 int nCore = 0;
@@ -778,6 +946,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                     }
                                 }
                             }
+#endif
                             if (ok) { done = true; rk = rkC; if (shortSet) nFoundLane = inRange; }
                             if (STATS) { wc.kept += (unsigned long long)k * __popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
                         }
@@ -830,29 +999,44 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 float ldScale = 0.f;
                 if (lit) ldScale = (distant ? 1.f : fallReg * __builtin_amdgcn_rcpf(d2Reg)) * ph * float(nLights);
                 const float kExit = -1.442695041f * exitLen;   // exp(-x) = exp2(-x log2 e)
+#if GRP_FLUX_MFMA
+                if (anyFlux) {   // every lane takes its own ray's column: CA <- bins 8g + c, CB <- bins 8g + 4 + c
+#pragma unroll
+                    for (int b = 0; b < 16; ++b) {
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(CA[b]), __float_as_uint(CB[b]), false, false);
+                        CA[b] = __uint_as_float(r[0]); CB[b] = __uint_as_float(r[1]);
+                    }
+                }
+#endif
                 if (act) {
+                    // per bin:  t = exp2(sT kRem) [ (sigA Le) stepE + (sigS stepD) (Ld + (albedo / sigS) acc liiScale) ],  fused multiply-adds
+                    // (values only: no decision hangs on them)
+                    const float liiU = useLii ? liiScale : 0.f;
 #pragma unroll
                     for (int qq = 0; qq < 8; ++qq) {
                         __builtin_amdgcn_sched_barrier(0);   // keep the constants of one bin quartet live at a time
-                        const f4 a4 = cA[qq], s4 = cS[qq], le4 = cLe[qq], al4 = cAl[qq], r4 = cRs[qq];
+                        const f4 t4 = cT[qq], s4 = cS[qq], al4 = cAL[qq], ar4 = cAR[qq];
                         const f4 i4 = REPLAY ? *reinterpret_cast<const f4 *>(L.lint + ln * 32 + 4 * qq) : cI[qq];
                         const f4 x4 = cX[qq], y4 = cY[qq], z4 = cZ[qq];
-                        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, lev[4] = {le4.x, le4.y, le4.z, le4.w};
-                        const float alv[4] = {al4.x, al4.y, al4.z, al4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w}, rv[4] = {r4.x, r4.y, r4.z, r4.w};
+                        const float tv[4] = {t4.x, t4.y, t4.z, t4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w}, alv[4] = {al4.x, al4.y, al4.z, al4.w};
+                        const float arv[4] = {ar4.x, ar4.y, ar4.z, ar4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w};
                         const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, yv[4] = {y4.x, y4.y, y4.z, y4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
                         for (int cc = 0; cc < 4; ++cc) {
                             const int b = 4 * qq + cc;
                             if (b >= 30) continue;
-                            const float sT = av[cc] + sv[cc];
-                            const float Pj = __builtin_amdgcn_exp2f(sT * kRem);
-                            const float Ld = (iv[cc] * ldScale) * __builtin_amdgcn_exp2f(sT * kExit);
-                            const float Lii = acc[b] * liiScale * rv[cc];
-                            const float Li = useLii ? Ld + alv[cc] * Lii : Ld;
-                            const float w = (av[cc] * lev[cc] * stepE) + (sv[cc] * Li * stepD);
+                            const float Pj = __builtin_amdgcn_exp2f(tv[cc] * kRem);
+                            const float Ld = iv[cc] * (ldScale * __builtin_amdgcn_exp2f(tv[cc] * kExit));
+#if GRP_FLUX_MFMA
+                            const float accB = (qq & 1) ? CB[4 * (qq >> 1) + cc] : CA[4 * (qq >> 1) + cc];
+#else
+                            const float accB = acc[b];
+#endif
+                            const float Li = __builtin_fmaf(arv[cc], accB * liiU, Ld);
+                            const float w = __builtin_fmaf(sv[cc] * stepD, Li, alv[cc] * stepE);
                             const float t = Pj * w;
                             if (SPECTRAL) Lv[b] += t;
-                            else { accX += xv[cc] * t; accY += yv[cc] * t; accZ += zv[cc] * t; }
+                            else { accX = __builtin_fmaf(xv[cc], t, accX); accY = __builtin_fmaf(yv[cc], t, accY); accZ = __builtin_fmaf(zv[cc], t, accZ); }
                         }
                     }
                     pPrev = p;
@@ -996,7 +1180,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
 
 extern "C" size_t pvol_group_lds_bytes(int candCap) {
     (void)candCap;
-    return (size_t)PREV_N * 4 + GRP_CH * 2 + (size_t)GRP_PITCH * 16 + GRP_U_BYTES + 9 * 32 * 4 + GRP_TRI_ROWS * 64 + PVOL_MAX_LIGHTS * 32 * 4;
+    return (size_t)PREV_N * 4 + GRP_CH * 2 + (size_t)GRP_PITCH * 16 + GRP_U_BYTES + 12 * 32 * 4 + GRP_TRI_ROWS * 64 + PVOL_MAX_LIGHTS * 32 * 4;
 }
 
 // replay: 0 = ray-parallel scenes (li_par_kernel's conditions), 1 = records of the RNG pre-pass, homogeneous, 2 = records, VolumeGrid

@@ -36,7 +36,8 @@
 #ifndef FXG_CORE
 #define FXG_CORE 1   // photons that are members for every lookup of a cluster are summed once for the wave
 #endif
-#define FXG_CAP 4096   // bucket slots: photon indices only (4 B each), eight times nused 500
+#define FXG_CAP 4080   // bucket slots: photon indices only (4 B each), eight times nused 500; (4080 + 8) x 4 B + the 4 KB that paint list and
+                       // histogram share = 20 448 B: eight waves per CU (two per SIMD, what 255 VGPRs allow)
 #define FXG_MINI 8
 #define FXG_TRIES 16  // radius corrections per lookup before the exact pass takes it
 
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
     float *bucket = reinterpret_cast<float *>(lds);
     const uint32_t *bIdx = reinterpret_cast<const uint32_t *>(lds);          // FXG_CAP + 8 photon indices
     uint32_t *paint = reinterpret_cast<uint32_t *>(lds) + (FXG_CAP + 8);
-    uint32_t *hist = paint + PAINT_CAP;   // [16 words][64 lanes]
+    uint32_t *hist = paint;   // [16 words][64 lanes]: the staging's paint list and the selection's histogram are never live together (PAINT_CAP = 16 x 64)
     Gather G;                             // the slow path's candidate lists alias the bucket (never live together)
     G.cap = S.candCap; G.cd = bucket; G.ci = reinterpret_cast<uint32_t *>(bucket + S.candCap); G.paint = paint;
     const GridView gv = volume_grid(S);
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
         float Twant = 0.f;
         float Tlo = 0.f, Thi = INFINITY;   // largest radius^2 seen to hold fewer than nused photons / smallest whose bucket overflowed
         int tries = 0;
+        float reach = 0.5f;       // a cluster takes the waiting lookups within this fraction of the pivot's radius of the pivot
         unsigned long long pending = __ballot(valid), slow = 0ull;
         float Trun;
 #ifdef PVOL_FXG_TIME
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
             // ---- cluster: the waiting lookups within half a radius of the pivot (all of a compact run, the first time)
             const float Tp = lane_f(Twant, piv);
             const float dPiv = len(p - c);
-            const bool in = waiting && dPiv <= 0.5f * sqrtf(Tp);
+            const bool in = waiting && dPiv <= lane_f(reach, piv) * sqrtf(Tp);
             const float Tmax = wave_max(in ? Twant : 0.f);
             const float spread = wave_max(in ? dPiv : 0.f);
             const float Rs = (sqrtf(Tmax) + spread) * 1.0001f + 1e-6f;
@@ -220,8 +222,14 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                     Thi = fminf(Thi, Twant);
                     Twant = Tlo > 0.f ? sqrtf(Tlo * Thi) : fminf(Twant * 0.62996f, Tprobe2);
                     // beside a beam the lane's own ball holds few photons while the cluster's (radius + spread) already reaches the
-                    // core: no radius serves both -- the wave-per-lookup pass looks at the lane's ball alone
-                    if (tries >= FXG_TRIES || (Tlo > 0.f && Thi < 1.25f * Tlo)) toSlowO = true;
+                    // core: no radius serves both.  Such lookups come in neighbourhoods: they wait for a TIGHTER cluster (their
+                    // bracket's upper end was learnt with the wide one and is forgotten); only when even a cluster of a sixteenth of
+                    // the radius overflows does the wave-per-lookup pass look at the lane's ball alone
+                    if (Tlo > 0.f && Thi < 1.25f * Tlo) {
+                        if (reach > 0.07f) { reach *= 0.35f; Thi = INFINITY; }   // Twant: the bracket's middle, as set above
+                        else toSlowO = true;
+                    }
+                    if (tries >= FXG_TRIES) toSlowO = true;
                 }
 #ifdef PVOL_FXG_DEBUG
                 { const int trp = lane_i(tries, piv); const float tl = lane_f(Tlo, piv), th = lane_f(Thi, piv), tw = lane_f(Twant, piv);
@@ -402,7 +410,11 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                 const float grow = nIn > 0 ? 1.35f * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf((float)k / (float)nIn)) : 8.f;
                 const float Tg = fminf(S.maxDistSq, Tl * fmaxf(1.5f, grow));
                 Twant = Tg < Thi ? Tg : sqrtf(Tlo * Thi);   // never back into a ball whose bucket overflowed
-                if (tries >= FXG_TRIES || Thi < 1.25f * Tlo) toSlow = true;
+                if (Thi < 1.25f * Tlo) {   // (as after an overflow: a tighter cluster first)
+                    if (reach > 0.07f) { reach *= 0.35f; Thi = INFINITY; Twant = Tg; }
+                    else toSlow = true;
+                }
+                if (tries >= FXG_TRIES) toSlow = true;
             }
 #ifdef PVOL_FXG_DEBUG
             { const unsigned long long fl = __ballot(failed && tries >= 8); if (fl) { const int j = __ffsll((long long)fl) - 1;
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
 
 extern "C" size_t pvol_fixgrp_lds_bytes(int candCap) {
     const size_t bucket = (size_t)(FXG_CAP + 8) * 4;
-    return std::max(bucket, (size_t)candCap * 8) + PAINT_CAP * 4 + 16 * LANES * 4;
+    static_assert(PAINT_CAP == 16 * LANES, "paint list and histogram share one region");
+    return std::max(bucket, (size_t)candCap * 8) + PAINT_CAP * 4;
 }
 #endif

@@ -171,6 +171,9 @@ __device__ __forceinline__ int stage_bucket(const DevScene &S, Gather &G, float 
 
 typedef float nf4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef GRP_PHASE_DIAG
+#define GRP_PHASE_DIAG 0   // 1 (stats build, timing only): diag0 / diag1 / diag3 / diag4 become the cycles of the prefix scan / pass 1 / pass 2 / bin b* ranking
+#endif
 #ifndef GRP_FLUX_MFMA
 #define GRP_FLUX_MFMA 1   // the flux sums of li_group_kernel on the matrix pipe (0: v_pk_fma_f32 with scalar-cache rows, the round-2 form)
 #endif
@@ -431,8 +434,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
             const V3 pEntry = o + d * t0;
             const bool inEntry = !GRID && hit && box_inside(S.extLo, S.extHi, xform_point(S.w2v, pEntry));
             const float tStart = t0 + pr.scatter_u * step;
-            int maxN = nS;
-            for (int off = 32; off > 0; off >>= 1) maxN = max(maxN, __shfl_xor(maxN, off));
+            const int maxN = (int)wave_max((float)nS);   // step counts are far below 2^24
             // ---- pre-loop: this ray's total optical length sum_j len_j (the geometry of the march, nothing else)
             float totalLen = 0.f;
             {
@@ -470,6 +472,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
             bool bad = false;
             wc.rays += __popcll(__ballot(have));
             for (int j = 0; j < maxN; ++j) {
+                const unsigned long long tq0 = (STATS && GRP_PHASE_DIAG == 2) ? stamp() : 0ull;
                 const bool act = j < nS;
                 const V3 p = o + d * tcur;
                 if (act) tcur += step;
@@ -537,6 +540,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 if (STATS) wc.unocc += __popcll(__ballot(lit));
                 const float kRem = -1.442695041f * (totalLen - cumLen);   // exp(-sigma_t R_j) = exp2(sigma_t * kRem)
                 const float stepD = step * dens;
+                const unsigned long long tq1 = (STATS && GRP_PHASE_DIAG == 2) ? stamp() : 0ull;
+                if (STATS && GRP_PHASE_DIAG == 2) wc.diag0 += tq1 - tq0;
                 // ---- k-NN gather of the group
                 // Raw flux sums of the step.  GRP_FLUX_MFMA: two 32 x 32 fp32 matrix accumulators (v_mfma_f32_32x32x2_f32, bit for bit an
                 // fmaf chain): rows = bins, columns = rays.  Lane l holds column (ray) l & 31 of CA (rays 0..31) and of CB (rays 32..63),
@@ -611,7 +616,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         if (STATS) { wc.tested += (unsigned long long)max(Mb, 0); wc.cySearch += stamp() - ts0; }
                         if (STATS) wc.diag5 += 1;
                         if (Mb < 0) {   // bucket overflow
-                            if (STATS) wc.diag1 += __popcll(__ballot(needP));
+                            if (STATS && !GRP_PHASE_DIAG) wc.diag1 += __popcll(__ballot(needP));
                             if (needP) { Twant = fixedR ? 0.f : 0.4f * Tl; lastFail = 1; }   // fixed radius: nothing smaller to try
                             continue;
                         }
@@ -631,6 +636,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         for (int wd = 0; wd <= GRP_BINS / 8; ++wd) histLane[wd * LANES] = 0u;
                         if (exact) grp_pass1<true>(bX, bY, bZ, Mb, pxy, pz_, scale, Tl, histLane);
                         else grp_pass1<false>(bX, bY, bZ, Mb, pxy, pz_, scale, Tl, histLane);
+                        const unsigned long long tpa = (STATS && GRP_PHASE_DIAG == 1) ? stamp() : 0ull;
+                        if (STATS && GRP_PHASE_DIAG == 1) wc.diag1 += tpa - tp1;
                         // ---- prefix scan: word of the k-th, then its nibble
                         int cum = 0, wsel = -1, cumWord = 0;
                         uint32_t selBits = 0u;
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         // the full radius holds fewer than k photons: all of them count, r^2 = the farthest (photonvolume.cpp:76-105)
                         const bool shortSet = sane && fullR && inRange < k;
                         const bool tooFew = needP && !fullR && cum < k;
-                        if (STATS && attempt == 0) wc.diag0 += __popcll(__ballot(needP && !ok && !shortSet));
+                        if (STATS && !GRP_PHASE_DIAG && attempt == 0) wc.diag0 += __popcll(__ballot(needP && !ok && !shortSet));
                         if (needP) {   // what to ask for next time (0 = nothing: crowded bin or wrapped counter, the exact lookup takes it)
                             Twant = 0.f;
                             lastFail = tooFew ? 2 : 3;
@@ -677,6 +684,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             }
                         }
                         const bool planLane = ok || shortSet;
+                        const unsigned long long tpb = (STATS && GRP_PHASE_DIAG == 1) ? stamp() : 0ull;
+                        if (STATS && GRP_PHASE_DIAG == 1) wc.diag0 += tpb - tpa;
                         if (__ballot(planLane)) {
                             // ---- pass 2: member bits
                             uint32_t mem[GRP_NW], le[GRP_NW];
@@ -690,6 +699,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             __syncthreads();
                             if (exact) grp_pass2<true>(bX, bY, bZ, Mb, pxy, pz_, th1, th2, mem, le, dmax);
                             else grp_pass2<false>(bX, bY, bZ, Mb, pxy, pz_, th1, th2, mem, le, dmax);
+                            const unsigned long long tpc = (STATS && GRP_PHASE_DIAG == 1) ? stamp() : 0ull;
+                            if (STATS && GRP_PHASE_DIAG == 1) wc.diag3 += tpc - tpb;
                             // ---- the photons of bin b*: their exact values into the lane's mini list (slot order)
                             int nb = 0;
 #pragma unroll
@@ -750,6 +761,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             if (shortSet) { ok = thOK; rkC = dmax; }
                             const unsigned long long tp3 = STATS ? stamp() : 0ull;
                             if (STATS) wc.cySelect += tp3 - tp1;
+                            if (STATS && GRP_PHASE_DIAG == 1) wc.diag4 += tp3 - tpc;
                             // ---- flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
                             // (constant address space: the map is read-only while this kernel runs) and cost no vector-memory
                             // bandwidth.  Two slots per iteration; acc = fma(row, 0 or 1, acc) is the exact addition for
@@ -973,13 +985,12 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 atomicOr(A.needSeq, 1u);   // list full: the batch is redone by the sequential kernel, never dropped
                             }
                         }
-                        if (STATS) { wc.retries += nfb; wc.diag3 += __popcll(__ballot(need && !done && lastFail == 1)); wc.diag4 += __popcll(__ballot(need && !done && lastFail == 2)); }
+                        if (STATS && !GRP_PHASE_DIAG) { wc.retries += nfb; wc.diag3 += __popcll(__ballot(need && !done && lastFail == 1)); wc.diag4 += __popcll(__ballot(need && !done && lastFail == 2)); }
                     }
                     // a k-th distance exists only for full sets; a short set says "search the full radius here"
                     const float rkGuess = (need && done) ? (nFoundLane >= k ? rk : S.maxDistSq) : 0.f;
                     {   // mean k-th distance^2 of the group at this step -> guess of the next group
-                        float sr = rkGuess, sn = rkGuess > 0.f ? 1.f : 0.f;
-                        for (int off = 32; off > 0; off >>= 1) { sr += __shfl_xor(sr, off); sn += __shfl_xor(sn, off); }
+                        const float sr = wave_sum(rkGuess), sn = (float)__popcll(__ballot(rkGuess > 0.f));
                         if (j < PREV_N && lane == 0 && sn > 0.f) prevRk[j] = sr / sn;
                     }
                     if (need) lastRk = rkGuess;
@@ -988,6 +999,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 //   w_j  = sigma_a Le step + sigma_s step (L_d + albedo L_ii)
                 //   L_ii = Sum(alpha) * phase / (4/3 pi r^3 sigma_s)                        (:99-105; acc holds the raw sum)
                 //   L_d  = I * [falloff / d^2] * exp(-sigma_t * exit) * phase * nLights      (:178-203)
+                const unsigned long long tq2 = (STATS && GRP_PHASE_DIAG == 2) ? stamp() : 0ull;
+                if (STATS && GRP_PHASE_DIAG == 2) wc.diag1 += tq2 - tq1;
                 float liiScale = 0.f;   // raw sum -> L_ii * sigma_s
                 if (need && done) {
                     const float dV = rk * sqrtf(rk);
@@ -1043,6 +1056,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                     inPrev = inP;
                     lenLast = lenStep;
                 }
+                if (STATS && GRP_PHASE_DIAG == 2) wc.diag3 += stamp() - tq2;
             }
             // ---- outputs
             if (have) {

@@ -82,6 +82,15 @@ __device__ __forceinline__ float wave_max(float v) {   // every lane gets the ma
     v = xor32_max(v);
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {   // every lane gets the sum over the wave (DPP + permlane swaps, no LDS)
+    v += dppf<DPP_QUAD_XOR1>(v);
+    v += dppf<DPP_QUAD_XOR2>(v);
+    v += dppf<DPP_ROW_HALF_MIRROR>(v);
+    v += dppf<DPP_ROW_ROR8>(v);
+    v = xor16_sum(v);
+    v = xor32_sum(v);
+    return v;
+}
 __device__ __forceinline__ uint32_t lanes_below(uint64_t mask, int lane) {
     return (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }

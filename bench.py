@@ -550,22 +550,28 @@ def main():
             res["parity_max_rel_l2"] = res["parity"]["max_rel_l2_per_pixel"]
             if not res["parity"]["ok"]:
                 rc = 3
-        # ---- roofline of the dominant kernel.  What binds it is VALU issue, not HBM (measured traffic is ~2 % of the 8 TB/s
-        # roof: the reference algorithm's bytes are served from one LDS bucket per 64 lookups and the scalar cache), so the
-        # fraction is taken against the vector-issue roof: 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction.
-        # VALU instructions per Li() call come from the rocprofv3 PMC passes of tools/pvol_prof on this kernel (profiles/).
+        # ---- roofline of the dominant kernel.  What binds it is the vector ALU, not HBM (measured traffic is ~10 % of the 8 TB/s
+        # roof: the reference algorithm's bytes are served from one LDS bucket per 64 lookups), so the fraction is the VALU pipe's
+        # busy time: 4 x SQ_ACTIVE_INST_VALU (the counter ticks once per four cycles a SIMD's vector pipe executes) against
+        # 1024 SIMDs x 2.4 GHz.  (Rounds 1-2 quoted the ISSUE rate, instructions / (SIMD-cycles / 2): it falls when instructions are
+        # removed, so it is kept as a secondary field only.)  Counters per Li() call come from the rocprofv3 PMC passes of
+        # tools/pvol_prof on this kernel (profiles/).
         steps_per_ray = work["n_steps"] / max(1, work["n_rays"]) if work["n_rays"] else None
         pmc = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             pmc = json.load(open(tpath))
+        peak_busy = 1024 * 2.4e9 / 1e9          # G SIMD-cycles / s
         peak_issue = 1024 * 2.4e9 / 2 / 1e9   # G wave-instructions / s
-        roof = {"bound": "valu_issue", "peak": peak_issue, "unit": "Gwaveinst/s", "kernel": kernel_name, "kernel_avg_ms": kms, "kernel_launches": launches,
+        roof = {"bound": "valu", "peak": peak_busy, "unit": "G SIMD-cycles/s", "kernel": kernel_name, "kernel_avg_ms": kms, "kernel_launches": launches,
                 "lookups_per_sample": steps_per_ray, "lookups_source": "device counter (n_steps / n_rays of the timed launches)"}
-        if pmc and kms > 0 and pmc.get("kernel") == kernel_name:
-            insts = pmc["valu_insts_per_ray"] * n_rays
-            roof["achieved"] = insts / (kms * 1e-3) / 1e9
-            roof["frac"] = roof["achieved"] / peak_issue
+        if pmc and kms > 0 and pmc.get("kernel") == kernel_name and pmc.get("valu_active_quadcycles_per_ray"):
+            roof["achieved"] = 4.0 * pmc["valu_active_quadcycles_per_ray"] * n_rays / (kms * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / peak_busy
+            roof["valu_issue_Gwaveinst_per_s"] = pmc["valu_insts_per_ray"] * n_rays / (kms * 1e-3) / 1e9
+            roof["valu_issue_frac"] = roof["valu_issue_Gwaveinst_per_s"] / peak_issue
+            if pmc.get("mfma_busy_cycles_per_ray"):
+                roof["mfma_pipe_busy_frac"] = pmc["mfma_busy_cycles_per_ray"] * n_rays / (kms * 1e-3) / 1e9 / peak_busy
             roof["traffic"] = pmc["hbm_bytes_per_ray"] * n_rays
             roof["hbm_measured_GBps"] = roof["traffic"] / (kms * 1e-3) / 1e9
             roof["hbm_frac_of_8TBps"] = roof["hbm_measured_GBps"] / 8000.0

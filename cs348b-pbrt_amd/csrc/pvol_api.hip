@@ -931,6 +931,7 @@ int pvol_launch_batch(pvol_ctx *c, const pvol_ray *dRays, uint32_t nRays, pvol_s
             }
             a.defer = c->dDefer; a.deferCount = c->dWords + 2; a.deferCap = (uint32_t)std::min<size_t>(c->deferCap, 0xffffffffu);
             a.fixGroup = (c->hs.nUsed > 100 && !getenv("PVOL_FIX_EXACT")) ? 1 : 0;   // GRP_PLAN_KMAX: see pvol_fixgrp_dev.h
+            { const char *ew = getenv("PVOL_FXG_WIDEN"), *ea = getenv("PVOL_FXG_AIM"); a.fxgWiden = ew ? (float)atof(ew) : 0.f; a.fxgAim = ea ? (float)atof(ea) : 0.f; }   // measurement knobs
             c->lastKernel = "li_group_kernel";
         }
         if (a.tauOut && !groupForm) return PVOL_E_UNSUPPORTED;

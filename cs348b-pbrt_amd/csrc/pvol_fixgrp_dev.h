@@ -68,14 +68,14 @@ __device__ __forceinline__ uint32_t box_count(const GridView &g, V3 c, float h, 
 
 // Radius^2 of the ball around c expected to hold ~1.4 k photons, from the photon counts of the grid cells around it (cube of
 // half side sqrt(T), at most four refinements of up to 20x the volume each).  Only a first guess: the lookups correct it.
-__device__ float probe_radius(const GridView &g, V3 c, float T0, int k, float maxT, int lane) {
+__device__ float probe_radius(const GridView &g, V3 c, float T0, int k, float maxT, int lane, float aim = 1.4f) {
     float T = fminf(T0, maxT);
     for (int it = 0; it < 4; ++it) {
         float vol;
         const uint32_t cnt = box_count(g, c, sqrtf(T), lane, &vol);
         const float pred = (float)cnt * (4.18879020478639f * T * sqrtf(T)) / vol;   // photons in the ball at the cube's density
-        const float want = 1.4f * (float)k;
-        if (pred >= 1.15f * (float)k && pred <= 2.0f * (float)k) break;
+        const float want = aim * (float)k;
+        if (pred >= fmaxf(1.05f, aim - 0.25f) * (float)k && pred <= (aim + 0.6f) * (float)k) break;
         if (pred < (float)k && T >= maxT) break;
         const float ratio = want / fmaxf(pred, 0.05f * want);
         T = fminf(maxT, T * __builtin_amdgcn_exp2f(0.6666667f * __builtin_amdgcn_logf(ratio)));
@@ -87,13 +87,13 @@ __device__ float probe_radius(const GridView &g, V3 c, float T0, int k, float ma
 // COMPACT (the lookups lie within a quarter of the probed radius of the first one: one staged bucket serves them all, lane per
 // lookup, li_fixup_group_kernel) or SCATTERED (few samples per pixel in a dense beam: every lookup has its own ball, and a wave
 // per lookup with 64 lanes on one candidate set is the better shape, li_fixup_kernel).  *Tprobe: first radius^2 for either.
-__device__ __forceinline__ bool fxg_compact(const GridView &g, const DevScene &S, bool valid, V3 p, int lane, float *Tprobe) {
+__device__ __forceinline__ bool fxg_compact(const GridView &g, const DevScene &S, bool valid, V3 p, int lane, float *Tprobe, float aim = 1.4f) {
     const unsigned long long m = __ballot(valid);
     *Tprobe = 0.f;
     if (!m) return false;
     const int piv = __ffsll((long long)m) - 1;
     const V3 c = v3(lane_f(p.x, piv), lane_f(p.y, piv), lane_f(p.z, piv));
-    const float T = probe_radius(g, c, S.rkEstimate, S.nUsed, S.maxDistSq, lane);
+    const float T = probe_radius(g, c, S.rkEstimate, S.nUsed, S.maxDistSq, lane, aim);
     *Tprobe = T;
     const float spread = wave_max(valid ? len(p - c) : 0.f);
     return spread <= 0.25f * sqrtf(T);
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
     const GridView gv = volume_grid(S);
     const int k = S.nUsed;
     const float wIso = 1.f / (4.f * K_PI);
+    const float widen = A.fxgWiden > 0.f ? A.fxgWiden : 1.3f, aim = A.fxgAim > 0.f ? A.fxgAim : 1.4f;
     const int q = lane & 7;
     const f4 sigA4 = ld4(S.sigA, q), sigS4 = ld4(S.sigS, q);
     const f4 sigT4 = sigA4 + sigS4;
@@ -185,14 +186,14 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
         float Trun;
 #ifdef PVOL_FXG_TIME
         unsigned long long tS = stamp();
-        if (!fxg_compact(gv, S, valid, p, lane, &Trun)) { FXG_T(cyProbe) ++nSkipped; continue; }
+        if (!fxg_compact(gv, S, valid, p, lane, &Trun, aim)) { FXG_T(cyProbe) ++nSkipped; continue; }
         FXG_T(cyProbe) ++nRuns;
 #else
-        if (!fxg_compact(gv, S, valid, p, lane, &Trun)) continue;   // empty, or scattered: li_fixup_kernel's
+        if (!fxg_compact(gv, S, valid, p, lane, &Trun, aim)) continue;   // empty, or scattered: li_fixup_kernel's
 #endif
         // the probe aims at 1.4 nused photons; the bucket holds eight times nused, and a ball that turns out too small costs a
         // second staging: start at about twice the probe's volume
-        if (valid) Twant = fminf(S.maxDistSq, Trun * 1.3f);
+        if (valid) Twant = fminf(S.maxDistSq, Trun * widen);
         int reprobes = 0;
         while (pending) {
             const bool waiting = ((pending >> lane) & 1ull) != 0ull;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
                 // seen to hold too few and this one for a lane that has been there, else half the volume
                 // (a run whose first point lies beside the beam the others are in was probed at the wrong place: probe again here)
                 float Tprobe2 = INFINITY;
-                if (reprobes < 3) { ++reprobes; Tprobe2 = 1.3f * probe_radius(gv, c, Tp * 0.5f, k, S.maxDistSq, lane); }
+                if (reprobes < 3) { ++reprobes; Tprobe2 = widen * probe_radius(gv, c, Tp * 0.5f, k, S.maxDistSq, lane, aim); }
                 bool toSlowO = false;
                 if (in) {
                     ++tries;

@@ -1151,7 +1151,7 @@ __global__ __launch_bounds__(LANES, (NREG > 4 ? PVOL_WPE_BIG : PVOL_WPE)) void l
     unsigned long long todo = __ballot(mine.ray != 0xffffffffu);
     if (A.fixGroup) {
         float Tprobe;
-        if (fxg_compact(gv, S, mine.ray != 0xffffffffu, v3(mine.px, mine.py, mine.pz), lane, &Tprobe)) continue;
+        if (fxg_compact(gv, S, mine.ray != 0xffffffffu, v3(mine.px, mine.py, mine.pz), lane, &Tprobe, A.fxgAim > 0.f ? A.fxgAim : 1.4f)) continue;
         if (Tprobe > 0.f) carry = Tprobe * (1.f / PVOL_GUESS_SCALE);
     }
     while (todo) {

@@ -33,6 +33,7 @@ struct LiArgs {
     uint32_t deferCap;
     float *tauOut;              // optional: per ray the optical length of Li()'s last march step (T = exp(-sigma_t * tau))
     int32_t fixGroup;           // nused beyond the bucket plan: the hand-over list is padded to 64-slot runs for li_fixup_group_kernel
+    float fxgWiden, fxgAim;     // li_fixup_group_kernel radius policy (0 = defaults), mirror of pvol_march.hip
 };
 struct GridBuildArgs {
     const float *p, *wi, *alpha;

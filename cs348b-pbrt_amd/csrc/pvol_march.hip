@@ -329,6 +329,7 @@ struct LiArgs {
     uint32_t deferCap;
     float *tauOut;              // optional: per ray the optical length of Li()'s last march step (T = exp(-sigma_t * tau))
     int32_t fixGroup;           // nused beyond the bucket plan: the hand-over list is padded to 64-slot runs for li_fixup_group_kernel
+    float fxgWiden, fxgAim;     // li_fixup_group_kernel's radius policy (0 = the defaults 1.3 / 1.4): first radius^2 = widen x the probe's, the probe aims at aim x nused photons
 };
 
 // PhotonVolumeIntegrator::Transmittance with sample == NULL (photonvolume.cpp:15-30)

@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_trace -- pyt
 echo "trace_exit=$?"
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM_RD" \
-            "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE"; do
+            "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"; do
     name=${pass%% *}
     timeout -k 10 300 rocprofv3 --pmc $pass --output-format csv -d $OUT/${TAG}_pmc_$name -- ./tools/pvol_prof /tmp/prof_in 1 > $OUT/${TAG}_pmc_$name.log 2>&1
     echo "$name exit=$?"

@@ -49,8 +49,10 @@ if agg and plain:
     json.dump(summary, open(os.path.join(out, tag + "_pmc_summary.json"), "w"), indent=1)
     json.dump({"kernel": "li_group_kernel", "hbm_bytes_per_ray": hbm / rays, "valu_insts_per_ray": agg.get("SQ_INSTS_VALU", 0) / rays,
                "salu_insts_per_ray": agg.get("SQ_INSTS_SALU", 0) / rays,
+               "valu_active_quadcycles_per_ray": agg.get("SQ_ACTIVE_INST_VALU", 0) / rays,
+               "mfma_busy_cycles_per_ray": agg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / rays, "mfma_insts_per_ray": agg.get("SQ_INSTS_MFMA", 0) / rays,
                "waves_per_simd": 3, "vgprs": 168,
-               "source": "profiles/%s_pmc_summary.json: SQ_INSTS_VALU / rays and (2*FETCH_SIZE + WRITE_SIZE)*1024 / rays, rocprofv3 --pmc passes of tools/pvol_prof on the bench's scene and device-shot map at 640x360, 256 spp" % tag},
+               "source": "profiles/%s_pmc_summary.json: SQ_ACTIVE_INST_VALU / rays, SQ_INSTS_VALU / rays and (2*FETCH_SIZE + WRITE_SIZE)*1024 / rays, rocprofv3 --pmc passes of tools/pvol_prof on the bench's scene and device-shot map at 640x360, 256 spp" % tag},
               open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
     print("hbm bytes/ray %.0f, L2 hit %.3f, VALU insts/ray %.0f" % (hbm / rays, summary["l2_hit_rate"], agg.get("SQ_INSTS_VALU", 0) / rays))
 _ks = glob.glob(os.path.join(g, tag + "_trace", "*", "*kernel_stats.csv"))

@@ -706,10 +706,11 @@ void pvol_phase_mark(pvol_ctx *c, hipStream_t stream, int id) {
 // draw count of every pixel is spread over several waves instead (tile_mw_kernel).  PVOL_TILE_WAVES overrides.
 static int tile_waves_per_task(const pvol_ctx *c, uint32_t nTasks) {
     if (c->tileWaves > 0) return c->tileWaves;
-    // measured on the C2 frame (tools/cmp_mt.sh, profiles/r03_tile_waves.txt): 8 tasks per CU 210 ms with one wave against 270 with eight,
-    // 4 per CU 197 against 145, 2 per CU 194 against 86
+    // measured on the C2 frame (tools/cmp_mt.sh, profiles/r03_tile_waves.txt): 16 tasks per CU 231 ms with one wave against 345 with two,
+    // 8 per CU 210 with one, 210 with two, 270 with eight; 4 per CU 198 with one, 132 with two, 144 with eight; 2 per CU 194 against 86
+    // with eight
     const double perCU = (double)nTasks / (double)std::max(1, c->nCU);
-    return perCU >= 6.0 ? 1 : 8;
+    return perCU >= 6.0 ? 1 : (perCU >= 3.0 ? 2 : 8);
 }
 
 // ---- specular recursion (pvol_spec_dev.h): the pool of segment rays of one batch (COUNT mode) or one slice (FUSED mode)

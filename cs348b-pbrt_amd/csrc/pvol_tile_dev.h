@@ -613,7 +613,8 @@ __global__ __launch_bounds__(LANES * NW) void tile_mw_kernel(LiArgs A, TileArgs 
                 T.xy[2 * ri + 1] = imageY;
                 mine += surfDraws;
             }
-            mine += tile_count_draws(S, CC, ltri, trows, o, d, maxt, su, blackS, lightBlack, 0u, slice, NSL);
+            if (!(T.debugSkip & 2u)) mine += tile_count_draws(S, CC, ltri, trows, o, d, maxt, su, blackS, lightBlack, 0u, slice, NSL);
+            else if (slice == 0) mine += 270ull;   // timing knob (PVOL_TIMING_KNOBS builds only)
         }
         for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
         if (lane == 0) part[wave] = mine;
@@ -621,8 +622,7 @@ __global__ __launch_bounds__(LANES * NW) void tile_mw_kernel(LiArgs A, TileArgs 
         if (wave == 0) {
             unsigned long long tot = lane < NW ? part[lane] : 0ull;
             for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-            rng_skip<true, W1>(rng, tot, lane);
-
+            if (!(T.debugSkip & 4u)) rng_skip<true, W1>(rng, tot, lane);   // (timing knob 4)
         }
     }
     if (wave == 0 && lane == 0) A.streams[sidx].end_draw = rng.draws;
@@ -643,7 +643,8 @@ static hipError_t launch_tile_t(const LiArgs *args, const TileArgs *tile, bool f
         const size_t bytes = partOff + 16 * 8;
         if (wavesPerTask >= 16) hipLaunchKernelGGL((tile_mw_kernel<16, SPEC>), grid, dim3(LANES * 16), bytes, stream, *args, *tile, partOff);
         else if (wavesPerTask >= 8) hipLaunchKernelGGL((tile_mw_kernel<8, SPEC>), grid, dim3(LANES * 8), bytes, stream, *args, *tile, partOff);
-        else hipLaunchKernelGGL((tile_mw_kernel<4, SPEC>), grid, dim3(LANES * 4), bytes, stream, *args, *tile, partOff);
+        else if (wavesPerTask >= 4) hipLaunchKernelGGL((tile_mw_kernel<4, SPEC>), grid, dim3(LANES * 4), bytes, stream, *args, *tile, partOff);
+        else hipLaunchKernelGGL((tile_mw_kernel<2, SPEC>), grid, dim3(LANES * 2), bytes, stream, *args, *tile, partOff);
         return hipGetLastError();
     }
     if (!fused) hipLaunchKernelGGL((tile_kernel<false, 4, SPEC>), grid, block, ldsBytes, stream, *args, *tile);

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
         L.cst[352 + lane] = lane < 30 ? __fdividef(s, a + s) * __builtin_amdgcn_rcpf(s) : 0.f;
     }
     __syncthreads();
-    const f4 *cA = reinterpret_cast<const f4 *>(L.cst), *cS = cA + 8, *cLe = cA + 16, *cAl = cA + 24, *cI = cA + 32, *cRs = cA + 40;
+    const f4 *cA = reinterpret_cast<const f4 *>(L.cst), *cS = cA + 8, *cI = cA + 32;
     const f4 *cX = cA + 48, *cY = cA + 56, *cZ = cA + 64, *cT = cA + 72, *cAL = cA + 80, *cAR = cA + 88;
     const bool rowsOK = !REPLAY && nLights > 0 && S.lights[0].kind == PVOL_LIGHT_DISTANT && S.nTris <= GRP_TRI_ROWS && !S.bvhNodes && !S.nSpheres;
     if (rowsOK) tri_rows_prepare(S, v3(S.lights[0].dir[0], S.lights[0].dir[1], S.lights[0].dir[2]), L.trows, lane);
@@ -781,6 +781,8 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             const int half = lane >> 5, binL = lane & 31;
                             typedef const __attribute__((address_space(1))) float gfloat;   // global_load, not flat_load
                             gfloat *alphaF = (gfloat *)(S.alpha4);
+                            float coreV[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, coreCs = 0.f;
+                            bool corePending = false;   // wave-uniform
                             if (GRP_CORE_MIN < GRP_CAP) {
                                 const bool anyOk = __ballot(ok) != 0ull;
                                 int nCore = 0;
@@ -805,31 +807,48 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                         basePos += __popcll(c64);
                                     }
                                     __syncthreads();
-                                    float cs = 0.f;
+                                    // all trips but the last are summed as they come; the LAST trip's rows stay in flight while the first
+                                    // batch of the per-slot rows below is requested (coreV / corePending)
                                     for (int c0 = 0; c0 < nCore; c0 += 16) {   // up to 16 rows in flight per trip
-                                        float v[8];
+                                        if (corePending) coreCs += ((coreV[0] + coreV[1]) + (coreV[2] + coreV[3])) + ((coreV[4] + coreV[5]) + (coreV[6] + coreV[7]));
 #pragma unroll
                                         for (int q2 = 0; q2 < 8; ++q2) {
                                             const int at = c0 + 2 * q2 + half;
                                             const bool on = at < nCore;
                                             const uint32_t idx = clist[on ? at : 0];
                                             const float w = alphaF[(size_t)idx * 32 + binL];
-                                            v[q2] = on ? w : 0.f;
+                                            coreV[q2] = on ? w : 0.f;
                                         }
-                                        cs += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+                                        corePending = true;
                                     }
-                                    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs), __float_as_uint(cs), false, false); cs = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-                                    const uint32_t okW = ok ? 1u : 0u;
-                                    auto ro = __builtin_amdgcn_permlane32_swap(okW, okW, false, false);
-                                    const float fA = half ? 0.f : (float)ro[0], fB = half ? 0.f : (float)ro[1];
-                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(cs, fA, CA, 0, 0, 0);
-                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(cs, fB, CB, 0, 0, 0);
                                     anyFlux = true;
 #pragma unroll
                                     for (int wd = 0; wd < GRP_NW; ++wd) mem[wd] &= ~coreW[wd];
                                     __syncthreads();
                                 }
                             }
+                            // software pipeline over the batches of slot pairs: the MFMAs of a batch are issued after the NEXT batch's rows
+                            // have been requested (pAv / pW1 / pW2 / pSel: the batch in flight), across bucket words
+                            float pAv[4] = {0.f, 0.f, 0.f, 0.f};
+                            uint32_t pW1 = 0u, pW2 = 0u, pSel = 0u;
+                            int pN = 0;          // pairs in the pending batch (wave-uniform)
+                            bool pOdd = false;   // its last pair is a single slot
+#define GRP_CONSUME_CORE() do { if (corePending) { \
+                                    coreCs += ((coreV[0] + coreV[1]) + (coreV[2] + coreV[3])) + ((coreV[4] + coreV[5]) + (coreV[6] + coreV[7])); \
+                                    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(coreCs), __float_as_uint(coreCs), false, false); coreCs = __uint_as_float(r[0]) + __uint_as_float(r[1]); } \
+                                    const uint32_t okW = ok ? 1u : 0u; \
+                                    auto ro = __builtin_amdgcn_permlane32_swap(okW, okW, false, false); \
+                                    const float fA = half ? 0.f : (float)ro[0], fB = half ? 0.f : (float)ro[1]; \
+                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(coreCs, fA, CA, 0, 0, 0); \
+                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(coreCs, fB, CB, 0, 0, 0); \
+                                    corePending = false; } } while (0)
+#define GRP_CONSUME_BATCH() do { _Pragma("unroll") for (int t = 0; t < 4; ++t) { \
+                                    if (t >= pN) continue;   /* wave-uniform */ \
+                                    const uint32_t sl = (pSel >> (8 * t)) & 31u; \
+                                    const bool live = !(pOdd && t == pN - 1) || !half;   /* an odd slot out: the upper half-wave contributes nothing */ \
+                                    const float f1 = live ? (float)((pW1 >> sl) & 1u) : 0.f, f2 = live ? (float)((pW2 >> sl) & 1u) : 0.f; \
+                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(pAv[t], f1, CA, 0, 0, 0); \
+                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(pAv[t], f2, CB, 0, 0, 0); } pN = 0; } while (0)
 #pragma unroll
                             for (int wd = 0; wd < GRP_NW; ++wd) {
                                 if (wd * 32 >= Mb) continue;
@@ -840,35 +859,37 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 if (!any) continue;
                                 anyFlux = true;
                                 const int idxW = (int)__float_as_uint(bI[wd * 32 + binL]);   // this word's photon indices, one per lane
-                                while (any) {   // four slot pairs per trip: their rows are requested before the first is used
-                                    int sel[4];
+                                while (any) {   // four slot pairs per batch
                                     float av[4];
-                                    bool on[4], two[4];
+                                    uint32_t selP = 0u;
+                                    int n = 0;
+                                    bool odd = false;
 #pragma unroll
                                     for (int t = 0; t < 4; ++t) {
-                                        on[t] = any != 0u;
-                                        const int b0 = on[t] ? __builtin_ctz(any) : 0;
-                                        any &= any - 1u;
-                                        two[t] = any != 0u;
-                                        const int b1 = two[t] ? __builtin_ctz(any) : b0;
-                                        any &= any - 1u;   // 0 & anything stays 0
-                                        sel[t] = half ? b1 : b0;
                                         av[t] = 0.f;
-                                        if (on[t]) {   // wave-uniform
-                                            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(idxW, b0), i1 = (uint32_t)__builtin_amdgcn_readlane(idxW, b1);
-                                            av[t] = alphaF[(size_t)(half ? i1 : i0) * 32 + binL];
-                                        }
+                                        if (any == 0u) continue;   // wave-uniform
+                                        const int b0 = __builtin_ctz(any);
+                                        any &= any - 1u;
+                                        const bool has2 = any != 0u;
+                                        const int b1 = has2 ? __builtin_ctz(any) : b0;
+                                        any &= any - 1u;   // 0 & anything stays 0
+                                        selP |= (uint32_t)(half ? b1 : b0) << (8 * t);
+                                        const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(idxW, b0), i1 = (uint32_t)__builtin_amdgcn_readlane(idxW, b1);
+                                        av[t] = alphaF[(size_t)(half ? i1 : i0) * 32 + binL];
+                                        n = t + 1;
+                                        odd = !has2;
                                     }
+                                    GRP_CONSUME_CORE();
+                                    GRP_CONSUME_BATCH();
 #pragma unroll
-                                    for (int t = 0; t < 4; ++t) {
-                                        if (!on[t]) continue;   // wave-uniform
-                                        const bool live = two[t] || !half;   // an odd slot out: the upper half-wave contributes nothing
-                                        const float f1 = live ? (float)((W1 >> sel[t]) & 1u) : 0.f, f2 = live ? (float)((W2 >> sel[t]) & 1u) : 0.f;
-                                        CA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], f1, CA, 0, 0, 0);
-                                        CB = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], f2, CB, 0, 0, 0);
-                                    }
+                                    for (int t = 0; t < 4; ++t) pAv[t] = av[t];
+                                    pW1 = W1; pW2 = W2; pSel = selP; pN = n; pOdd = odd;
                                 }
                             }
+                            GRP_CONSUME_CORE();
+                            GRP_CONSUME_BATCH();
+#undef GRP_CONSUME_CORE
+#undef GRP_CONSUME_BATCH
 #else
                             if (GRP_CORE_MIN < GRP_CAP) {
                                 const bool anyOk = __ballot(ok) != 0ull;

@@ -174,9 +174,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef GRP_PHASE_DIAG
 #define GRP_PHASE_DIAG 0   // 1 (stats build, timing only): diag0 / diag1 / diag3 / diag4 become the cycles of the prefix scan / pass 1 / pass 2 / bin b* ranking
 #endif
-#ifndef GRP_FLUX_MFMA
-#define GRP_FLUX_MFMA 1   // the flux sums of li_group_kernel on the matrix pipe (0: v_pk_fma_f32 with scalar-cache rows, the round-2 form)
-#endif
 
 // OR over the wave, every lane gets it (DPP + permlane swaps, no LDS)
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
@@ -543,20 +540,14 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 const unsigned long long tq1 = (STATS && GRP_PHASE_DIAG == 2) ? stamp() : 0ull;
                 if (STATS && GRP_PHASE_DIAG == 2) wc.diag0 += tq1 - tq0;
                 // ---- k-NN gather of the group
-                // Raw flux sums of the step.  GRP_FLUX_MFMA: two 32 x 32 fp32 matrix accumulators (v_mfma_f32_32x32x2_f32, bit for bit an
+                // Raw flux sums of the step: two 32 x 32 fp32 matrix accumulators (v_mfma_f32_32x32x2_f32, bit for bit an
                 // fmaf chain): rows = bins, columns = rays.  Lane l holds column (ray) l & 31 of CA (rays 0..31) and of CB (rays 32..63),
                 // register i = bin 8 (i >> 2) + (i & 3) + 4 (l >> 5).  After the attempts 16 v_permlane32_swap leave every lane its OWN
                 // ray's 32 bins: CA[i] = bin 8 (i >> 2) + (i & 3), CB[i] = the same + 4.
-#if GRP_FLUX_MFMA
                 f32x16 CA, CB;
 #pragma unroll
                 for (int b = 0; b < 16; ++b) { CA[b] = 0.f; CB[b] = 0.f; }
                 bool anyFlux = false;   // wave-uniform
-#else
-                float acc[32];
-#pragma unroll
-                for (int b = 0; b < 32; ++b) acc[b] = 0.f;
-#endif
                 float rk = 0.f;
                 int nFoundLane = k;
                 const bool need = inP && S.nPhotons > 0u && useLiiAny;
@@ -762,18 +753,6 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             const unsigned long long tp3 = STATS ? stamp() : 0ull;
                             if (STATS) wc.cySelect += tp3 - tp1;
                             if (STATS && GRP_PHASE_DIAG == 1) wc.diag4 += tp3 - tpc;
-                            // ---- flux.  Row addresses are wave-uniform: the rows come through the scalar cache into SGPRs
-                            // (constant address space: the map is read-only while this kernel runs) and cost no vector-memory
-                            // bandwidth.  Two slots per iteration; acc = fma(row, 0 or 1, acc) is the exact addition for
-                            // members and a no-op for the others, without a branch.
-                            typedef const __attribute__((address_space(4))) nf4 cf4;
-                            // ---- shared part of the flux.  The 64 query points of a group-step lie within a fraction of the
-                            // k-NN radius of each other, so a good half of every lane's k photons are the SAME photons: the slots
-                            // that are members for EVERY served lane (AND of the member words) are summed once for the wave --
-                            // lane b (and b + 32 for every second slot) adds bin b of their rows, one coalesced 128-B row per
-                            // half-wave load -- and handed to the lanes by 30 readlanes; the per-lane loop below then runs over
-                            // the remaining slots only.  Addition order changes, nothing else.
-#if GRP_FLUX_MFMA
                             // ---- flux on the matrix pipe.  A = alpha rows (lane l: bin l & 31 of the slot of its half-wave: one coalesced
                             // 128-B row per half-wave and load), B = member bits of ray l & 31 for that slot as 0.f / 1.f (the upper
                             // half-wave's copy of a ray's word comes from ONE v_permlane32_swap per 32 slots): D = A B + C adds a row to exactly
@@ -781,8 +760,6 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             const int half = lane >> 5, binL = lane & 31;
                             typedef const __attribute__((address_space(1))) float gfloat;   // global_load, not flat_load
                             gfloat *alphaF = (gfloat *)(S.alpha4);
-                            float coreV[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, coreCs = 0.f;
-                            bool corePending = false;   // wave-uniform
                             if (GRP_CORE_MIN < GRP_CAP) {
                                 const bool anyOk = __ballot(ok) != 0ull;
                                 int nCore = 0;
@@ -807,48 +784,31 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                         basePos += __popcll(c64);
                                     }
                                     __syncthreads();
-                                    // all trips but the last are summed as they come; the LAST trip's rows stay in flight while the first
-                                    // batch of the per-slot rows below is requested (coreV / corePending)
+                                    float cs = 0.f;
                                     for (int c0 = 0; c0 < nCore; c0 += 16) {   // up to 16 rows in flight per trip
-                                        if (corePending) coreCs += ((coreV[0] + coreV[1]) + (coreV[2] + coreV[3])) + ((coreV[4] + coreV[5]) + (coreV[6] + coreV[7]));
+                                        float v[8];
 #pragma unroll
                                         for (int q2 = 0; q2 < 8; ++q2) {
                                             const int at = c0 + 2 * q2 + half;
                                             const bool on = at < nCore;
                                             const uint32_t idx = clist[on ? at : 0];
                                             const float w = alphaF[(size_t)idx * 32 + binL];
-                                            coreV[q2] = on ? w : 0.f;
+                                            v[q2] = on ? w : 0.f;
                                         }
-                                        corePending = true;
+                                        cs += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
                                     }
+                                    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs), __float_as_uint(cs), false, false); cs = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
+                                    const uint32_t okW = ok ? 1u : 0u;
+                                    auto ro = __builtin_amdgcn_permlane32_swap(okW, okW, false, false);
+                                    const float fA = half ? 0.f : (float)ro[0], fB = half ? 0.f : (float)ro[1];
+                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(cs, fA, CA, 0, 0, 0);
+                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(cs, fB, CB, 0, 0, 0);
                                     anyFlux = true;
 #pragma unroll
                                     for (int wd = 0; wd < GRP_NW; ++wd) mem[wd] &= ~coreW[wd];
                                     __syncthreads();
                                 }
                             }
-                            // software pipeline over the batches of slot pairs: the MFMAs of a batch are issued after the NEXT batch's rows
-                            // have been requested (pAv / pW1 / pW2 / pSel: the batch in flight), across bucket words
-                            float pAv[4] = {0.f, 0.f, 0.f, 0.f};
-                            uint32_t pW1 = 0u, pW2 = 0u, pSel = 0u;
-                            int pN = 0;          // pairs in the pending batch (wave-uniform)
-                            bool pOdd = false;   // its last pair is a single slot
-#define GRP_CONSUME_CORE() do { if (corePending) { \
-                                    coreCs += ((coreV[0] + coreV[1]) + (coreV[2] + coreV[3])) + ((coreV[4] + coreV[5]) + (coreV[6] + coreV[7])); \
-                                    { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(coreCs), __float_as_uint(coreCs), false, false); coreCs = __uint_as_float(r[0]) + __uint_as_float(r[1]); } \
-                                    const uint32_t okW = ok ? 1u : 0u; \
-                                    auto ro = __builtin_amdgcn_permlane32_swap(okW, okW, false, false); \
-                                    const float fA = half ? 0.f : (float)ro[0], fB = half ? 0.f : (float)ro[1]; \
-                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(coreCs, fA, CA, 0, 0, 0); \
-                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(coreCs, fB, CB, 0, 0, 0); \
-                                    corePending = false; } } while (0)
-#define GRP_CONSUME_BATCH() do { _Pragma("unroll") for (int t = 0; t < 4; ++t) { \
-                                    if (t >= pN) continue;   /* wave-uniform */ \
-                                    const uint32_t sl = (pSel >> (8 * t)) & 31u; \
-                                    const bool live = !(pOdd && t == pN - 1) || !half;   /* an odd slot out: the upper half-wave contributes nothing */ \
-                                    const float f1 = live ? (float)((pW1 >> sl) & 1u) : 0.f, f2 = live ? (float)((pW2 >> sl) & 1u) : 0.f; \
-                                    CA = __builtin_amdgcn_mfma_f32_32x32x2f32(pAv[t], f1, CA, 0, 0, 0); \
-                                    CB = __builtin_amdgcn_mfma_f32_32x32x2f32(pAv[t], f2, CB, 0, 0, 0); } pN = 0; } while (0)
 #pragma unroll
                             for (int wd = 0; wd < GRP_NW; ++wd) {
                                 if (wd * 32 >= Mb) continue;
@@ -859,127 +819,35 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                                 if (!any) continue;
                                 anyFlux = true;
                                 const int idxW = (int)__float_as_uint(bI[wd * 32 + binL]);   // this word's photon indices, one per lane
-                                while (any) {   // four slot pairs per batch
+                                while (any) {   // four slot pairs per trip: their rows are requested before the first is used
+                                    int sel[4];
                                     float av[4];
-                                    uint32_t selP = 0u;
-                                    int n = 0;
-                                    bool odd = false;
+                                    bool on[4], two[4];
 #pragma unroll
                                     for (int t = 0; t < 4; ++t) {
-                                        av[t] = 0.f;
-                                        if (any == 0u) continue;   // wave-uniform
-                                        const int b0 = __builtin_ctz(any);
+                                        on[t] = any != 0u;
+                                        const int b0 = on[t] ? __builtin_ctz(any) : 0;
                                         any &= any - 1u;
-                                        const bool has2 = any != 0u;
-                                        const int b1 = has2 ? __builtin_ctz(any) : b0;
+                                        two[t] = any != 0u;
+                                        const int b1 = two[t] ? __builtin_ctz(any) : b0;
                                         any &= any - 1u;   // 0 & anything stays 0
-                                        selP |= (uint32_t)(half ? b1 : b0) << (8 * t);
-                                        const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(idxW, b0), i1 = (uint32_t)__builtin_amdgcn_readlane(idxW, b1);
-                                        av[t] = alphaF[(size_t)(half ? i1 : i0) * 32 + binL];
-                                        n = t + 1;
-                                        odd = !has2;
-                                    }
-                                    GRP_CONSUME_CORE();
-                                    GRP_CONSUME_BATCH();
-#pragma unroll
-                                    for (int t = 0; t < 4; ++t) pAv[t] = av[t];
-                                    pW1 = W1; pW2 = W2; pSel = selP; pN = n; pOdd = odd;
-                                }
-                            }
-                            GRP_CONSUME_CORE();
-                            GRP_CONSUME_BATCH();
-#undef GRP_CONSUME_CORE
-#undef GRP_CONSUME_BATCH
-#else
-                            if (GRP_CORE_MIN < GRP_CAP) {
-                                const bool anyOk = __ballot(ok) != 0ull;
-                                int nCore = 0;
-                                uint32_t coreW[GRP_NW];
-#pragma unroll
-                                for (int wd = 0; wd < GRP_NW; ++wd) {
-                                    coreW[wd] = 0u;
-                                    if (wd * 32 >= Mb || !anyOk) continue;
-                                    coreW[wd] = (uint32_t)__builtin_amdgcn_readfirstlane((int)~wave_or(ok ? ~mem[wd] : 0u));
-                                    nCore += __builtin_popcount(coreW[wd]);
-                                }
-                                if (nCore >= GRP_CORE_MIN) {
-                                    // compact list of the core slots' photon indices (the mini-list columns are free by now)
-                                    uint32_t *clist = reinterpret_cast<uint32_t *>(L.miniD);
-                                    int basePos = 0;
-#pragma unroll
-                                    for (int r2 = 0; r2 < GRP_NW / 2; ++r2) {
-                                        if (r2 * 64 >= Mb) continue;
-                                        const unsigned long long c64 = (unsigned long long)coreW[2 * r2] | ((unsigned long long)coreW[2 * r2 + 1] << 32);
-                                        if ((c64 >> lane) & 1ull) clist[basePos + (int)lanes_below(c64, lane)] = __float_as_uint(bI[r2 * 64 + lane]);
-                                        basePos += __popcll(c64);
-                                    }
-                                    __syncthreads();
-                                    // eight rows per load: lane l reads the (l & 7)-th float4 of the row of list entry 8 q + (l >> 3)
-                                    const int sub = lane >> 3, quart = lane & 7;
-                                    nf4 cs4 = {0.f, 0.f, 0.f, 0.f};
-                                    for (int c0 = 0; c0 < nCore; c0 += 32) {   // up to 32 rows in flight per trip
-                                        nf4 v[4];
-#pragma unroll
-                                        for (int q = 0; q < 4; ++q) {
-                                            const int at = c0 + 8 * q + sub;
-                                            const bool on = at < nCore;
-                                            const uint32_t idx = clist[on ? at : 0];
-                                            const float4 w = S.alpha4[(size_t)idx * 8 + quart];
-                                            v[q] = on ? nf4{w.x, w.y, w.z, w.w} : nf4{0.f, 0.f, 0.f, 0.f};
+                                        sel[t] = half ? b1 : b0;
+                                        av[t] = 0.f;
+                                        if (on[t]) {   // wave-uniform
+                                            const uint32_t i0 = (uint32_t)__builtin_amdgcn_readlane(idxW, b0), i1 = (uint32_t)__builtin_amdgcn_readlane(idxW, b1);
+                                            av[t] = alphaF[(size_t)(half ? i1 : i0) * 32 + binL];
                                         }
-                                        cs4 += (v[0] + v[1]) + (v[2] + v[3]);
-                                    }
-                                    // sum over the eight row groups (lane bits 3, 4, 5): every lane with the same quartet holds the total
-                                    float csv[4] = {cs4.x, cs4.y, cs4.z, cs4.w};
-#pragma unroll
-                                    for (int cc = 0; cc < 4; ++cc) {
-                                        float x = csv[cc];
-                                        x += dppf<DPP_ROW_ROR8>(x);
-                                        { auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-                                        { auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false); x = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-                                        csv[cc] = x;
-                                    }
-                                    const float okf = ok ? 1.f : 0.f;
-#pragma unroll
-                                    for (int b = 0; b < 30; ++b)
-                                        acc[b] = __builtin_fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(csv[b & 3]), b >> 2)), okf, acc[b]);
-#pragma unroll
-                                    for (int wd = 0; wd < GRP_NW; ++wd) mem[wd] &= ~coreW[wd];
-                                    __syncthreads();
-                                }
-                            }
-#pragma unroll
-                            for (int wd = 0; wd < GRP_NW; ++wd) {
-                                if (wd * 32 >= Mb) continue;
-                                const uint32_t mine = ok ? mem[wd] : 0u;
-                                uint32_t any = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or(mine));
-                                if (!any) continue;
-                                const int idxW = (int)__float_as_uint(bI[wd * 32 + (lane & 31)]);   // this word's photon indices, one per lane
-                                while (any) {
-                                    const int b0 = __builtin_ctz(any);
-                                    any &= any - 1u;
-                                    const bool two = any != 0u;
-                                    const int b1 = two ? __builtin_ctz(any) : b0;
-                                    any &= any - 1u;   // 0 & anything stays 0
-                                    cf4 *ra = (cf4 *)(S.alpha4 + (size_t)(uint32_t)__builtin_amdgcn_readlane(idxW, b0) * 8);
-                                    cf4 *rb = (cf4 *)(S.alpha4 + (size_t)(uint32_t)__builtin_amdgcn_readlane(idxW, b1) * 8);
-                                    nf4 rowA[8], rowB[8];
-#pragma unroll
-                                    for (int qq = 0; qq < 8; ++qq) { rowA[qq] = ra[qq]; rowB[qq] = rb[qq]; }
-                                    const float fA = (float)((mine >> b0) & 1u), fB = two ? (float)((mine >> b1) & 1u) : 0.f;
-#pragma unroll
-                                    for (int qq = 0; qq < 8; ++qq) {
-                                        acc[4 * qq] = __builtin_fmaf(rowA[qq].x, fA, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowA[qq].y, fA, acc[4 * qq + 1]);
-                                        acc[4 * qq + 2] = __builtin_fmaf(rowA[qq].z, fA, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowA[qq].w, fA, acc[4 * qq + 3]);
                                     }
 #pragma unroll
-                                    for (int qq = 0; qq < 8; ++qq) {
-                                        acc[4 * qq] = __builtin_fmaf(rowB[qq].x, fB, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rowB[qq].y, fB, acc[4 * qq + 1]);
-                                        acc[4 * qq + 2] = __builtin_fmaf(rowB[qq].z, fB, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rowB[qq].w, fB, acc[4 * qq + 3]);
+                                    for (int t = 0; t < 4; ++t) {
+                                        if (!on[t]) continue;   // wave-uniform
+                                        const bool live = two[t] || !half;   // an odd slot out: the upper half-wave contributes nothing
+                                        const float f1 = live ? (float)((W1 >> sel[t]) & 1u) : 0.f, f2 = live ? (float)((W2 >> sel[t]) & 1u) : 0.f;
+                                        CA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], f1, CA, 0, 0, 0);
+                                        CB = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], f2, CB, 0, 0, 0);
                                     }
                                 }
                             }
-#endif
                             if (ok) { done = true; rk = rkC; if (shortSet) nFoundLane = inRange; }
                             if (STATS) { wc.kept += (unsigned long long)k * __popcll(__ballot(ok)); wc.cyFlux += stamp() - tp3; }
                         }
@@ -1033,7 +901,6 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                 float ldScale = 0.f;
                 if (lit) ldScale = (distant ? 1.f : fallReg * __builtin_amdgcn_rcpf(d2Reg)) * ph * float(nLights);
                 const float kExit = -1.442695041f * exitLen;   // exp(-x) = exp2(-x log2 e)
-#if GRP_FLUX_MFMA
                 if (anyFlux) {   // every lane takes its own ray's column: CA <- bins 8g + c, CB <- bins 8g + 4 + c
 #pragma unroll
                     for (int b = 0; b < 16; ++b) {
@@ -1041,7 +908,6 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                         CA[b] = __uint_as_float(r[0]); CB[b] = __uint_as_float(r[1]);
                     }
                 }
-#endif
                 if (act) {
                     // per bin:  t = exp2(sT kRem) [ (sigA Le) stepE + (sigS stepD) (Ld + (albedo / sigS) acc liiScale) ],  fused multiply-adds
                     // (values only: no decision hangs on them)
@@ -1061,11 +927,7 @@ __global__ __launch_bounds__(LANES, GRP_WPE) void li_group_kernel(LiArgs A) {
                             if (b >= 30) continue;
                             const float Pj = __builtin_amdgcn_exp2f(tv[cc] * kRem);
                             const float Ld = iv[cc] * (ldScale * __builtin_amdgcn_exp2f(tv[cc] * kExit));
-#if GRP_FLUX_MFMA
                             const float accB = (qq & 1) ? CB[4 * (qq >> 1) + cc] : CA[4 * (qq >> 1) + cc];
-#else
-                            const float accB = acc[b];
-#endif
                             const float Li = __builtin_fmaf(arv[cc], accB * liiU, Ld);
                             const float w = __builtin_fmaf(sv[cc] * stepD, Li, alv[cc] * stepE);
                             const float t = Pj * w;

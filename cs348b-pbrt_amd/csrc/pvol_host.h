@@ -7,34 +7,7 @@
 #include "pvol_dev.h"
 
 // ---- kernels' host entry points (pvol_march.hip, pvol_grid.hip)
-struct LiArgs {
-    const DevScene *scene;
-    const pvol_ray *rays;
-    pvol_stream *streams;
-    uint32_t nStreams;
-    uint32_t nRays;
-    int outputKind;
-    float *out;
-    uint32_t *draws;
-    const uint32_t *initState;
-    uint32_t *finalState;
-    DevCounters *counters;
-    int transmittanceOnly;
-    uint32_t *chunkCounter;
-    uint32_t *needSeq;
-    int gated;
-    unsigned char *records;
-    uint32_t recStride, sliceM, sliceK;
-    uint32_t *state;
-    float grpGuess;
-    int liteResolve;
-    DeferRec *defer;            // li_group_kernel: lookups handed to li_fixup_kernel
-    uint32_t *deferCount;
-    uint32_t deferCap;
-    float *tauOut;              // optional: per ray the optical length of Li()'s last march step (T = exp(-sigma_t * tau))
-    int32_t fixGroup;           // nused beyond the bucket plan: the hand-over list is padded to 64-slot runs for li_fixup_group_kernel
-    float fxgWiden, fxgAim;     // li_fixup_group_kernel radius policy (0 = defaults), mirror of pvol_march.hip
-};
+#include "pvol_liargs.h"
 struct GridBuildArgs {
     const float *p, *wi, *alpha;
     uint32_t n;

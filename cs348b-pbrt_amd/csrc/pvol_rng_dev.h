@@ -49,8 +49,8 @@ template <bool WG1> __device__ __forceinline__ void rng_sync() {
 //    -- other lanes' results -- through LDS.  Compiler barriers between "last old load | first store" and "stores of A, B |
 //    loads of the new words"; every load unconditional (clamped index).  (8 waves per task, 512 tasks: 98 ms; volatile loop 217.)
 #define PVOL_COMPILER_BARRIER() asm volatile("" ::: "memory")
-template <bool WG1 = true> __device__ void mt_regenerate(uint32_t *mt_, int lane) {
-    if (WG1) {
+template <bool WG1 = true, bool TWO_RT = !WG1> __device__ void mt_regenerate(uint32_t *mt_, int lane) {
+    if (!TWO_RT) {
         volatile uint32_t *mt = mt_;
         for (int base = 0; base < MT_N - MT_M; base += LANES) {
             const int kk = base + lane;
@@ -126,11 +126,13 @@ template <bool SEQ, bool WG1 = true> __device__ __forceinline__ uint32_t rng_uin
 template <bool SEQ> __device__ __forceinline__ float rng_float(Rng &r, int lane) {
     return (rng_uint<SEQ>(r, lane) & 0xffffff) / float(1 << 24);   // core/rng.cpp:59-65
 }
-template <bool SEQ, bool WG1 = true> __device__ __forceinline__ void rng_skip(Rng &r, unsigned long long n, int lane) {
+// TWO_RT: the two-round-trip regeneration at THIS site whatever the workgroup's shape (the tile pre-pass's per-trip advance: ~31
+// regenerations back to back, 0.33 us each alone against 1.4 us for the volatile loop, tools/mt_probe.hip)
+template <bool SEQ, bool WG1 = true, bool TWO_RT = !WG1> __device__ __forceinline__ void rng_skip(Rng &r, unsigned long long n, int lane) {
     r.draws += n;
     if (!SEQ) return;
     while (n > 0) {
-        if (r.mti >= MT_N) { mt_regenerate<WG1>(r.mt, lane); r.mti = 0; }
+        if (r.mti >= MT_N) { mt_regenerate<WG1, TWO_RT>(r.mt, lane); r.mti = 0; }
         unsigned long long avail = (unsigned long long)(MT_N - r.mti);
         unsigned long long take = n < avail ? n : avail;
         r.mti += (int)take;

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
                 // wave total (integer adds in any order are exact)
                 unsigned long long tot = nd + surfDraws;
                 for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
-                if (!(T.debugSkip & 4u)) rng_skip<true>(rng, tot, lane);
+                if (!(T.debugSkip & 4u)) rng_skip<true, true, true>(rng, tot, lane);
 
             } else {
                 for (int j = 0; j < cnt; ++j) {

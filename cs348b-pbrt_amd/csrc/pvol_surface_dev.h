@@ -251,7 +251,13 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
     for (int i = 0; i < 3; ++i) { cg.gridLo[i] = S.surf.gridLo[i]; cg.gdim[i] = S.surf.gdim[i]; }
     cg.cellStart = S.surf.cellStart; cg.subStart = 0; cg.pos4 = S.surf.pos4;
     const int k = S.surf.nLookup;
-    for (unsigned long long g0 = (unsigned long long)blockIdx.x * LANES; g0 < A.nRays; g0 += (unsigned long long)gridDim.x * LANES) {
+    // groups of 64 samples in runs of sixteen (four 256-spp pixels) per wave: the search radius that served one group is the first
+    // guess for the next (the caustic density changes slowly along a wall)
+    const float maxDist = sqrtf(S.surf.maxDistSq);
+    float Rtry = maxDist;   // wave-uniform
+    const unsigned long long nGroups = (A.nRays + LANES - 1) / LANES;
+    for (unsigned long long gi = (unsigned long long)blockIdx.x * 16ull; gi < nGroups; gi = ((gi & 15ull) == 15ull) ? gi + 1ull + ((unsigned long long)gridDim.x - 1ull) * 16ull : gi + 1ull) {
+        const unsigned long long g0 = gi * LANES;
         const size_t ri = (size_t)g0 + lane;
         const bool have = ri < A.nRays;
         const pvol_ray pr = A.rays[have ? ri : 0];
@@ -291,8 +297,14 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
         // those within maxdist of the first waiting sample's hit point, and that sample alone if even this bucket overflows.
         const bool needAny = lambert && S.surf.nPhotons > 0u;
         unsigned long long pending = __ballot(needAny);
-        const float maxDist = sqrtf(S.surf.maxDistSq);
         bool alone = false;
+        // Where more photons lie within maxdist of the samples than the bucket holds (a caustic's focus; the beam's footprint on a wall),
+        // the nused nearest lie far inside maxdist: the cluster is then searched with a SMALLER radius -- halved area per overflow,
+        // bracketed between a radius that overflowed and one that held fewer than nused for some sample -- and a sample is served as
+        // soon as nused photons lie inside the searched ball (they are its nused nearest).  Only when no radius serves the cluster
+        // does one sample at a time go through the full-radius path (round 2 went there at the first overflow: 64 stagings, or 64
+        // streamed lookups, per group of samples -- 3.1 s of a 4.9 s C2 frame with the scene's surface integrator on).
+        float Rhi = INFINITY, Rlo = 0.f;   // wave-uniform (Rtry carries over from the previous group)
         while (pending) {
             const bool waiting = ((pending >> lane) & 1ull) != 0ull;
             const float big = 3.0e38f;
@@ -312,14 +324,24 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
                 need = waiting && (alone ? dPiv == 0.f : dPiv <= maxDist);
                 rho = alone ? 0.f : maxDist;
             }
-            const float Rs = (maxDist + rho) * 1.0001f + 1e-6f;
+            const float Rq = alone ? maxDist : Rtry;
+            const float Rs = (Rq + rho) * 1.0001f + 1e-6f;
             unsigned long long tst = 0;
             __syncthreads();
             const int Mb = stage_bucket_g<SRF_CAP>(cg, G, bucket, c, Rs, lane, tst);
-            if (Mb < 0 && !alone) { alone = true; continue; }   // retry with the first waiting sample on its own
-            pending &= ~__ballot(need);
+            if (Mb < 0 && !alone) {   // overflow: a smaller ball, or -- the bracket closed -- the first waiting sample on its own
+                Rhi = Rq;
+                // (a cluster whose own spread overflows the bucket cannot be helped by a smaller ball: every trip either serves a sample,
+                // narrows the bracket or -- below a tenth of maxdist, or below the spread -- ends in the one-sample path: the loop ends)
+                if ((Rlo > 0.f && Rhi < 1.1f * Rlo) || Rq < 0.1f * maxDist || Rq < rho) alone = true;
+                else Rtry = Rlo > 0.f ? sqrtf(Rlo * Rhi) : 0.70710678f * Rq;
+                continue;
+            }
+            const float T2 = (alone || !(Rq < maxDist)) ? S.surf.maxDistSq : Rq * Rq;   // the searched ball's radius^2
+            const bool wasAlone = alone;
             alone = false;
             if (Mb < 0) {   // more photons within maxdist of ONE point than the bucket holds: streamed from the grid for that point
+                pending &= ~__ballot(need);
                 float sa[32];
                 caustic_stream(S, cg, c, dot(lane_v3(h.nn, pivLane), lane_v3(wo, pivLane)) < 0.f ? lane_v3(h.nn, pivLane) * -1.f : lane_v3(h.nn, pivLane), k, lane, sa);
                 if (need) {
@@ -330,66 +352,184 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
                 // pass A: how many photons lie inside maxdist (kdtree.h:180: dist2 < maxDistSquared), and -- when that is at least
                 // nused -- the nused-th smallest distance^2 by bisection over the fp32 bit pattern (the heap of PhotonProcess keeps
                 // the nused nearest and leaves maxDistSquared at the farthest of them)
+                // (round 3: the nused-th distance^2 comes from three histogram passes as in li_fixup_group_kernel -- 64 bins on [0, maxdist^2)
+                // with 8-bit counters, 64 sub-bins of the bin that holds it, the <= 8 members of that sub-bin ordered in registers --
+                // instead of ~30 bisection passes over the bucket, which were 3 s of a C2 frame with the scene's surface integrator on;
+                // the bisection remains for a lane whose counters wrapped or whose sub-bin is crowded)
+                uint32_t *hist = G.paint;   // [16 words][64 lanes]: the paint list is dead once the bucket is staged
+                const float hscale = 64.f / T2;
                 int nIn = 0;
+                fxg_clear(hist, lane);
+                __syncthreads();
                 for (int i = 0; i < Mb; ++i) {
                     const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
-                    nIn += (need && dx * dx + dy * dy + dz * dz < S.surf.maxDistSq) ? 1 : 0;
+                    const float d2 = dx * dx + dy * dy + dz * dz;
+                    const bool inside = need && d2 < T2;
+                    nIn += inside ? 1 : 0;
+                    const uint32_t bin = (uint32_t)fminf(d2 * hscale, 63.f);
+                    atomicAdd(&hist[(bin >> 2) * LANES + lane], inside ? 1u << ((bin & 3u) << 3) : 0u);
                 }
-                float r2 = S.surf.maxDistSq;
+                __syncthreads();
+                float r2 = T2;
                 uint32_t kth = 0xffffffffu;   // members: d2 < maxDistSq when fewer than nused lie inside, else the nused nearest
                 int tieQuota = 0;
                 if (__ballot(nIn >= k)) {
-                    uint32_t lo = 0u, hi = __float_as_uint(S.surf.maxDistSq);
                     const bool sel = nIn >= k;
-                    while (__ballot(sel && lo < hi)) {   // smallest bit pattern v with count(d2 <= v) >= k
-                        const uint32_t mid = lo + ((hi - lo) >> 1);
-                        int cnt = 0;
-                        for (int i = 0; i < Mb; ++i) {
-                            const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
-                            cnt += (__float_as_uint(dx * dx + dy * dy + dz * dz) <= mid) ? 1 : 0;
-                        }
-                        if (sel && lo < hi) { if (cnt >= k) hi = mid; else lo = mid + 1u; }
+                    bool fast = sel;   // the histogram passes hold for this lane
+                    uint32_t bstar = 0u, below = 0u, inBin = 0u, total = 0u;
+                    const bool f1 = fxg_scan(hist, lane, (uint32_t)k, &bstar, &below, &inBin, &total);
+                    if (!f1 || total != (uint32_t)nIn) fast = false;   // a byte wrapped
+                    const float fb = (float)bstar;
+                    fxg_clear(hist, lane);
+                    __syncthreads();
+                    for (int i = 0; i < Mb; ++i) {
+                        const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                        const float d2 = dx * dx + dy * dy + dz * dz;
+                        const float f = d2 * hscale;
+                        const bool hitB = fast && d2 < T2 && (uint32_t)fminf(f, 63.f) == bstar;
+                        const uint32_t sub = (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f);
+                        atomicAdd(&hist[(sub >> 2) * LANES + lane], hitB ? 1u << ((sub & 3u) << 3) : 0u);
                     }
-                    if (sel) {
-                        kth = lo;
-                        r2 = __uint_as_float(lo);
-                        int less = 0;
+                    __syncthreads();
+                    uint32_t sstar = 0u, below2 = 0u, inSub = 0u, total2 = 0u;
+                    const uint32_t need1 = (uint32_t)k - below;   // rank of the nused-th inside its bin, >= 1
+                    const bool f2 = fxg_scan(hist, lane, need1, &sstar, &below2, &inSub, &total2);
+                    if (!f2 || total2 != inBin || inSub > 8u) fast = false;
+                    float mini[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) mini[m] = INFINITY;
+                    if (__ballot(fast)) {
                         for (int i = 0; i < Mb; ++i) {
                             const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
-                            less += (__float_as_uint(dx * dx + dy * dy + dz * dz) < kth) ? 1 : 0;
+                            const float d2 = dx * dx + dy * dy + dz * dz;
+                            const float f = d2 * hscale;
+                            const bool hitC = fast && d2 < T2 && (uint32_t)fminf(f, 63.f) == bstar &&
+                                              (uint32_t)fminf(fmaxf((f - fb) * 64.f, 0.f), 63.f) == sstar;
+                            if (__ballot(hitC)) {
+                                float v = hitC ? d2 : INFINITY;   // insertion into the ascending list
+#pragma unroll
+                                for (int m = 0; m < 8; ++m) { const float lo = fminf(mini[m], v); v = fmaxf(mini[m], v); mini[m] = lo; }
+                            }
                         }
-                        tieQuota = k - less;   // photons AT the k-th distance^2 that still belong (bucket order)
+                    }
+                    if (fast) {
+                        const uint32_t need2 = need1 - below2;   // 1 .. inSub
+                        float kv = mini[0];
+#pragma unroll
+                        for (int m = 1; m < 8; ++m) kv = (need2 == (uint32_t)(m + 1)) ? mini[m] : kv;
+                        int lessInList = 0;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) lessInList += mini[m] < kv ? 1 : 0;
+                        kth = __float_as_uint(kv);
+                        r2 = kv;
+                        tieQuota = k - (int)(below + below2) - lessInList;
+                    }
+                    // the lanes the histograms could not serve: bisection over the fp32 bit pattern (the heap of PhotonProcess keeps the
+                    // nused nearest and leaves maxDistSquared at the farthest of them)
+                    const bool slowSel = sel && !fast;
+                    if (__ballot(slowSel)) {
+                        uint32_t lo = 0u, hi = __float_as_uint(T2);
+                        while (__ballot(slowSel && lo < hi)) {   // smallest bit pattern v with count(d2 <= v) >= k
+                            const uint32_t mid = lo + ((hi - lo) >> 1);
+                            int cnt = 0;
+                            for (int i = 0; i < Mb; ++i) {
+                                const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                                cnt += (__float_as_uint(dx * dx + dy * dy + dz * dz) <= mid) ? 1 : 0;
+                            }
+                            if (slowSel && lo < hi) { if (cnt >= k) hi = mid; else lo = mid + 1u; }
+                        }
+                        if (slowSel) {
+                            kth = lo;
+                            r2 = __uint_as_float(lo);
+                            int less = 0;
+                            for (int i = 0; i < Mb; ++i) {
+                                const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                                less += (__float_as_uint(dx * dx + dy * dy + dz * dz) < kth) ? 1 : 0;
+                            }
+                            tieQuota = k - less;   // photons AT the k-th distance^2 that still belong (bucket order)
+                        }
+                    }
+                }
+                // a sample is served when its nused nearest lie inside the searched ball, or the ball is the full one
+                const bool served = need && (nIn >= k || !(T2 < S.surf.maxDistSq));
+                pending &= ~__ballot(served);
+                if (!wasAlone) {
+                    // photons on a surface: the count grows with the radius squared.  The next ball aims at 1.6 nused photons for the
+                    // sparsest sample (smaller buckets make every pass cheaper), inside the bracket if there is one
+                    const int minIn = -(int)wave_max(need ? -(float)nIn : -3.0e9f);
+                    const float aim = Rq * sqrtf(1.6f * (float)k / (float)max(minIn, 1));
+                    if (__ballot(need && !served)) {   // fewer than nused inside the reduced ball for some sample: a larger one next
+                        Rlo = Rq;
+                        if (Rhi < INFINITY && Rhi < 1.1f * Rlo) alone = true;
+                        else Rtry = fminf(maxDist, Rhi < INFINITY ? fminf(fmaxf(aim, 1.05f * Rq), sqrtf(Rlo * Rhi)) : fmaxf(aim, 1.25f * Rq));
+                    } else {   // the next cluster / group starts from the radius that fits this one, with an open bracket
+                        Rlo = 0.f; Rhi = INFINITY;
+                        Rtry = fminf(maxDist, fmaxf(aim, 0.1f * maxDist));
                     }
                 }
                 // pass B: Lr = sum over members on the wo side of  kernel / (nPaths r^2) * alpha   (the -wo side carries rho_t == 0)
                 const V3 Nf = dot(h.nn, wo) < 0.f ? h.nn * -1.f : h.nn;
                 const float norm = 1.f / ((float)S.surf.nCausticPaths * r2);
+                // acc[sample][bin] += weight[sample][photon] * alpha[photon][bin] on the matrix pipe (v_mfma_f32_32x32x2_f32 is bit for
+                // bit the fmaf chain the per-lane loop made, bucket order kept): A = two flux rows (lane l: bin l & 31 of the photon of
+                // its half-wave, one coalesced 128-B row per half-wave), B = the two photons' weights for sample l & 31 -- ONE
+                // v_permlane32_swap of (w0, w1) builds both operands --, samples 0..31 into CA, 32..63 into CB.  The round-2 loop
+                // read every row through the scalar cache and waited for it, photon by photon: 3.1 s of a 4.9 s C2 frame with the
+                // scene's own surface integrator (buckets of 500-2000 caustic photons where the light enters).
+                f32x16 CA, CB;
+#pragma unroll
+                for (int b = 0; b < 16; ++b) { CA[b] = 0.f; CB[b] = 0.f; }
+                const int half = lane >> 5, binL = lane & 31;
+                typedef const __attribute__((address_space(1))) float gfloat;
+                typedef const __attribute__((address_space(1))) nf4 gfloat4;
+                gfloat *alphaF = (gfloat *)(S.surf.alpha4);
+                gfloat4 *wiG = (gfloat4 *)(S.surf.wi4);
+                for (int i0 = 0; i0 < Mb; i0 += 8) {   // four photon pairs per trip: their rows are requested before the first is used
+                    float av[4], w0[4], w1[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        av[t] = 0.f; w0[t] = 0.f; w1[t] = 0.f;
+                        const int ia = i0 + 2 * t, ib = ia + 1;
+                        if (ia >= Mb) continue;   // wave-uniform
+                        const bool two = ib < Mb;
+                        const uint32_t pa = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[ia]));
+                        const uint32_t pb = two ? (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[ib])) : pa;
+                        av[t] = alphaF[(size_t)(half ? pb : pa) * 32 + binL];
+                        const nf4 wiA = wiG[pa], wiB = wiG[pb];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {   // bucket order: the tie quota is spent in it
+                            if (u == 1 && !two) continue;
+                            const int i = ia + u;
+                            const nf4 wi4 = u ? wiB : wiA;
+                            const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
+                            const float d2 = dx * dx + dy * dy + dz * dz;
+                            bool mem = served && d2 < T2;
+                            if (kth != 0xffffffffu) {
+                                const uint32_t bits = __float_as_uint(d2);
+                                mem = served && bits < kth;
+                                if (served && bits == kth && tieQuota > 0) { mem = true; --tieQuota; }
+                            }
+                            const float sW = 1.f - d2 / r2;
+                            float wgt = (3.f * 0.31830988618379067154f * sW * sW) * norm;
+                            if (!mem || !(Nf.x * wi4.x + Nf.y * wi4.y + Nf.z * wi4.z > 0.f)) wgt = 0.f;
+                            if (u) w1[t] = wgt; else w0[t] = wgt;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (i0 + 2 * t >= Mb) continue;   // wave-uniform
+                        if (!__ballot(w0[t] != 0.f || w1[t] != 0.f)) continue;
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(w0[t]), __float_as_uint(w1[t]), false, false);
+                        CA = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], __uint_as_float(r[0]), CA, 0, 0, 0);
+                        CB = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], __uint_as_float(r[1]), CB, 0, 0, 0);
+                    }
+                }
                 float acc[32];
 #pragma unroll
-                for (int b = 0; b < 32; ++b) acc[b] = 0.f;
-                typedef const __attribute__((address_space(4))) nf4 cf4;
-                for (int i = 0; i < Mb; ++i) {
-                    const float dx = bX[i] - h.p.x, dy = bY[i] - h.p.y, dz = bZ[i] - h.p.z;
-                    const float d2 = dx * dx + dy * dy + dz * dz;
-                    bool mem = need && d2 < S.surf.maxDistSq;
-                    if (kth != 0xffffffffu) {
-                        const uint32_t bits = __float_as_uint(d2);
-                        mem = need && bits < kth;
-                        if (need && bits == kth && tieQuota > 0) { mem = true; --tieQuota; }
-                    }
-                    const uint32_t pidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bI[i]));
-                    const f4 wi4 = S.surf.wi4[pidx];
-                    const float sW = 1.f - d2 / r2;
-                    float wgt = (3.f * 0.31830988618379067154f * sW * sW) * norm;
-                    if (!mem || !(Nf.x * wi4.x + Nf.y * wi4.y + Nf.z * wi4.z > 0.f)) wgt = 0.f;
-                    if (!__ballot(wgt != 0.f)) continue;
-                    cf4 *row = (cf4 *)(S.surf.alpha4 + (size_t)pidx * 8);
-#pragma unroll
-                    for (int qq = 0; qq < 8; ++qq) {
-                        const nf4 rr = row[qq];
-                        acc[4 * qq] = __builtin_fmaf(rr.x, wgt, acc[4 * qq]); acc[4 * qq + 1] = __builtin_fmaf(rr.y, wgt, acc[4 * qq + 1]);
-                        acc[4 * qq + 2] = __builtin_fmaf(rr.z, wgt, acc[4 * qq + 2]); acc[4 * qq + 3] = __builtin_fmaf(rr.w, wgt, acc[4 * qq + 3]);
-                    }
+                for (int b = 0; b < 16; ++b) {   // every lane takes its own sample's column: CA <- bins 8 g + c, CB <- bins 8 g + 4 + c
+                    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(CA[b]), __float_as_uint(CB[b]), false, false);
+                    acc[8 * (b >> 2) + (b & 3)] = __uint_as_float(r[0]);
+                    acc[8 * (b >> 2) + 4 + (b & 3)] = __uint_as_float(r[1]);
                 }
 #pragma unroll
                 for (int b = 0; b < 30; ++b) Ls[b] += acc[b] * mat.kd[b] * 0.31830988618379067154f;   // Lr * rho(wo) * INV_PI, rho == Kd

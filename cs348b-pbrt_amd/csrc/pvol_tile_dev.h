@@ -79,18 +79,23 @@ __device__ void tile_pixel_sample(const TileArgs &T, TileLds &L, Rng &rng, int l
         rng_sync<WG1>();
         tile_shuffle<WG1>(L.time, n, 1, L.oth, rng, lane, (T.debugSkip & 1u) != 0u);
     }
+    // the arrays nobody reads (light / BSDF / gather samples of the surface integrator) are drawn, not kept: their draws are skipped,
+    // whole runs of them at once -- thousands per pixel with a final gather's 2 x 32 samples -- through the two-round-trip regeneration
+    unsigned long long pend = 0ull;
     for (uint32_t a = 0; a < T.n1dCount; ++a) {
         if (a == T.scatterIndex) {   // n1d == 1 (checked on the host)
+            if (pend) { rng_skip<true, WG1, true>(rng, pend, lane); pend = 0ull; }
             const uint32_t s = rng_uint<true, WG1>(rng, lane);
             for (uint32_t i = lane; i < n; i += LANES) L.scatter[i] = van_der_corput(i, s);
             rng_skip<true, WG1>(rng, n, lane);
             rng_sync<WG1>();
             tile_shuffle<WG1>(L.scatter, n, 1, L.oth, rng, lane, (T.debugSkip & 1u) != 0u);
         } else {
-            rng_skip<true, WG1>(rng, 1ull + (unsigned long long)T.n1d[a] * n + n, lane);
+            pend += 1ull + (unsigned long long)T.n1d[a] * n + n;
         }
     }
-    for (uint32_t a = 0; a < T.n2dCount; ++a) rng_skip<true, WG1>(rng, 2ull + (unsigned long long)T.n2d[a] * n + n, lane);
+    for (uint32_t a = 0; a < T.n2dCount; ++a) pend += 2ull + (unsigned long long)T.n2d[a] * n + n;
+    if (pend) rng_skip<true, WG1, true>(rng, pend, lane);
 }
 
 // PerspectiveCamera::GenerateRayDifferential without a lens + CameraToWorld (static transform)

@@ -231,7 +231,10 @@ __device__ __forceinline__ void grp_pass1(const float *bX, const float *bY, cons
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t bin = grp_bin<EXACT>(dd[u], scale, Tl);
-            atomicAdd(&histLane[(bin >> 3) * LANES], 1u << ((bin & 7u) << 2));   // ds_add_u32, no return
+            // word = bits 3..6 of the bin as ONE v_bfe_u32 (the plain shift-and-mask form costs the compiler a shift, a mask and an add)
+            uint32_t word;
+            asm("v_bfe_u32 %0, %1, 3, 4" : "=v"(word) : "v"(bin));   // (an intrinsic is folded back into shift + mask)
+            atomicAdd(&histLane[word * LANES], 1u << ((bin & 7u) << 2));   // ds_add_u32, no return
         }
     }
 }

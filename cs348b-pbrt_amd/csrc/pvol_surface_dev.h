@@ -10,8 +10,9 @@
 //   sample = T * Lsurface + Lvi        (SamplerRenderer::Li, renderers/samplerrenderer.cpp:238-250)
 // Not covered (the host refuses such scenes when the surface integrator is on): specular BSDFs (the recursion of
 // SpecularReflect/Transmit), an indirect map / final gather, VolumeGrid media (the shadow-ray tau() offset is a drawn value).
+#define SRF_AIM 1.6f    // the search ball is re-aimed at this multiple of nused photons for the sparsest sample of a cluster
 #define SRF_CAP 1024   // caustic bucket capacity (photons within the search ball + spread of a group's hit points).  Measured on the C2 frame with the
-                       // scene's surface integrator on: 2048 -> 1 509 ms, 1024 -> 1 104 ms, 512 -> 3 580 ms: occupancy (LDS) against overflows
+                       // scene's surface integrator on: 2048 -> 1 509 ms, 1024 -> 1 104 ms, 512 -> 3 580 ms; 640 with SRF_AIM 1.35: 1 278 ms: occupancy (LDS) against overflows
 
 struct SurfHit {
     int tri, mat;
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
                     // photons on a surface: the count grows with the radius squared.  The next ball aims at 1.6 nused photons for the
                     // sparsest sample (smaller buckets make every pass cheaper), inside the bracket if there is one
                     const int minIn = -(int)wave_max(need ? -(float)nIn : -3.0e9f);
-                    const float aim = Rq * sqrtf(1.6f * (float)k / (float)max(minIn, 1));
+                    const float aim = Rq * sqrtf(SRF_AIM * (float)k / (float)max(minIn, 1));
                     if (__ballot(need && !served)) {   // fewer than nused inside the reduced ball for some sample: a larger one next
                         Rlo = Rq;
                         if (Rhi < INFINITY && Rhi < 1.1f * Rlo) alone = true;

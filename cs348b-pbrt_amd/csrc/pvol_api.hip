@@ -710,7 +710,10 @@ static int tile_waves_per_task(const pvol_ctx *c, uint32_t nTasks) {
     // 8 per CU 210 with one, 210 with two, 270 with eight; 4 per CU 198 with one, 132 with two, 144 with eight; 2 per CU 194 against 86
     // with eight
     const double perCU = (double)nTasks / (double)std::max(1, c->nCU);
-    return perCU >= 6.0 ? 1 : (perCU >= 3.0 ? 2 : 8);
+    // (second pass, with the multi-wave kernels held to two waves per SIMD -- 256 VGPRs, so that the workgroups of ALL a CU's tasks are resident:
+    // 4 per CU 77 ms with two waves (134 before), 99 with four; 2 per CU 56.5 ms with four waves, 80.8 with eight at 128 VGPRs, 85.9 at 256)
+    // 8 per CU: 131.5 ms with two waves, 146.9 with one; 16 per CU: 174.7 with one, 190.7 with two
+    return perCU >= 12.0 ? 1 : (perCU >= 3.0 ? 2 : 4);
 }
 
 // ---- specular recursion (pvol_spec_dev.h): the pool of segment rays of one batch (COUNT mode) or one slice (FUSED mode)

@@ -527,9 +527,11 @@ __global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, Ti
 // (64 at a time) and the march steps of its slice (tile_count_draws: steps dealt round-robin), the partial counts meet in LDS.
 // Two workgroup barriers per pixel; the stream only ever needs the pixel's TOTAL, so one skip replaces the per-trip skips.
 template <int NW, bool SPEC>
-// (eight waves per task: four waves per SIMD asked for, i.e. 128 VGPRs -- with 256 a CU holds ONE task's workgroup at a time, and a 512-task
-// rank has two tasks per CU)
-__global__ __launch_bounds__(LANES * NW, (NW >= 8 ? 4 : 1)) void tile_mw_kernel(LiArgs A, TileArgs T, uint32_t partOff) {
+// Register budget = residency: the kernel wants ~340 VGPRs, and at that size a CU holds one wave per SIMD -- ONE task's workgroup (four waves)
+// or two tasks' (two waves) at a time, while a rank of an 8-GPU frame has two tasks per CU and one of a 4-GPU frame four.  Two waves per SIMD
+// (256 VGPRs, 83 spilled) keeps every task of the CU resident: 512-task pre-pass 85.9 (eight waves, 256 VGPRs) -> 56.5 ms (four waves),
+// 1 024-task pre-pass 134 -> 77 ms (two waves).  Eight and sixteen waves per task ask for four per SIMD (128 VGPRs).
+__global__ __launch_bounds__(LANES * NW, (NW >= 8 ? 4 : 2)) void tile_mw_kernel(LiArgs A, TileArgs T, uint32_t partOff) {
     extern __shared__ __align__(16) unsigned char lds[];
     constexpr bool W1 = (NW == 1);   // a one-wave workgroup (debugging form) may use the workgroup barrier inside the RNG helpers
     const DevScene &S = *A.scene;

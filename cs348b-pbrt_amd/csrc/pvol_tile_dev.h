@@ -345,7 +345,7 @@ struct SpecWalkPol {
 // SPEC: the scene holds a specular material and the surface integrator is on (the recursion of pvol_spec_dev.h is compiled in;
 // kept out of the other instantiations, whose register allocation it would otherwise weigh down)
 template <bool FUSED, int NREG, bool SPEC>
-__global__ __launch_bounds__(LANES, FUSED ? 1 : 4) void tile_kernel(LiArgs A, TileArgs T) {
+__global__ __launch_bounds__(LANES, FUSED ? 2 : 4) void tile_kernel(LiArgs A, TileArgs T) {   // FUSED: 256 VGPRs (it wants 385: one wave per SIMD, four tasks per CU at a time)
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;

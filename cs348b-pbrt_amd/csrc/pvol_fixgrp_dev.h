@@ -165,7 +165,10 @@ __global__ __launch_bounds__(LANES, 2) void li_fixup_group_kernel(LiArgs A) {
         _Pragma("unroll") for (int u = 0; u < 8; ++u) id_[u] = (uint32_t)__builtin_amdgcn_readfirstlane((int)iv[u]);         \
         _Pragma("unroll") for (int u = 0; u < 8; ++u) P_[u] = posRows[id_[u]];                                                \
     }
-    for (uint32_t r0 = blockIdx.x * (uint32_t)LANES; r0 < n; r0 += gridDim.x * (uint32_t)LANES) {
+    // eight consecutive runs per wave at a time (neighbouring runs are the same rays one march step apart: their buckets overlap)
+    const uint32_t nRuns = (n + (uint32_t)LANES - 1u) / (uint32_t)LANES;
+    for (uint32_t runI = blockIdx.x * 8u; runI < nRuns; runI = ((runI & 7u) == 7u) ? runI + 1u + (gridDim.x - 1u) * 8u : runI + 1u) {
+        const uint32_t r0 = runI * (uint32_t)LANES;
         const uint32_t e = r0 + (uint32_t)lane;
         DeferRec r;
         r.ray = 0xffffffffu; r.px = r.py = r.pz = 0.f; r.kRem = 0.f; r.stepD = 0.f; r.guess = 0.f; r.dens = 1.f;

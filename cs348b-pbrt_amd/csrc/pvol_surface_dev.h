@@ -236,7 +236,7 @@ __device__ __attribute__((noinline)) void caustic_stream(const DevScene &S, cons
 
 // One camera sample per lane, 64 consecutive samples (one pixel's, at >= 64 spp) per group: their hit points lie within a
 // pixel footprint, so the caustic lookups share one LDS bucket of the photons within maxdist + spread of the group's centre.
-__global__ __launch_bounds__(LANES, 3) void surface_kernel(SurfArgs A) {
+__global__ __launch_bounds__(LANES, 2) void surface_kernel(SurfArgs A) {   // 256 VGPRs: its 20.5 KB of LDS allow seven waves per CU anyway (at 168 VGPRs it spilled 531)
     extern __shared__ __align__(16) unsigned char lds[];
     const DevScene &S = *A.scene;
     const int lane = threadIdx.x;
